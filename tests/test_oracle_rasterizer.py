@@ -1,0 +1,207 @@
+"""CPU tests that pin oracle/rasterizer_ref.c:
+known-answer tests + cross-check against the independent float64 autograd
+formulation in tests/ref_torch64.py.  No GPU needed."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import rasterizer_oracle as O
+import ref_torch64 as R64
+
+syn = pkg("synthetic")
+
+
+def small_scene(P=60, W=40, H=24, seed=0, s0=0.12, max_opacity=1.0, deg=3):
+    cam = syn.look_at_camera(W, H)
+    g = syn.make_gaussians(P, seed, s0)
+    a = syn.activate(g)
+    a["opacities"] = np.minimum(a["opacities"], np.float32(max_opacity))
+    return a, cam
+
+
+def run_oracle(a, cam, deg=3, bg=(1, 1, 1), colors_precomp=None, cov3D_precomp=None, scale_modifier=1.0):
+    return O.forward(np.asarray(bg, np.float32), a["means3D"], colors_precomp, a["opacities"],
+                     None if cov3D_precomp is not None else a["scales"],
+                     None if cov3D_precomp is not None else a["rotations"], scale_modifier, cov3D_precomp,
+                     cam.viewmatrix, cam.projmatrix, cam.tanfovx, cam.tanfovy, cam.image_height, cam.image_width,
+                     None if colors_precomp is not None else a["sh"], deg, cam.campos)
+
+
+def cover_masks(r):
+    """(P,H,W) bool: pixels inside each Gaussian's tile rectangle (auxiliary.h:46-56 semantics, numpy float32)."""
+    P, W, H = r["P"], r["W"], r["H"]
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    out = np.zeros((P, H, W), bool)
+    for i in range(P):
+        rad = int(r["radii"][i])
+        if rad <= 0:
+            continue
+        px, py = np.float32(r["means2D"][i, 0]), np.float32(r["means2D"][i, 1])
+        f = np.float32
+        x0 = min(gx, max(0, int((px - f(rad)) / f(16))))
+        y0 = min(gy, max(0, int((py - f(rad)) / f(16))))
+        x1 = min(gx, max(0, int((px + f(rad) + f(16) - f(1)) / f(16))))
+        y1 = min(gy, max(0, int((py + f(rad) + f(16) - f(1)) / f(16))))
+        out[i, y0 * 16:y1 * 16, x0 * 16:x1 * 16] = True
+    return torch.from_numpy(out)
+
+
+def to64(x, grad=False):
+    t = torch.tensor(np.asarray(x), dtype=torch.float64)
+    return t.requires_grad_(grad)
+
+
+# ---------------------------------------------------------------- KATs
+
+def test_higher_msb():
+    # rasterizer_impl.cu:35-50: position of the highest set bit + 1 (number of bits needed)
+    for n, want in [(1, 1), (2, 2), (3, 2), (4, 3), (2040, 11), (2500, 12), (5440, 13), (32400, 15), (65535, 16)]:
+        assert O.higher_msb(n) == want
+
+
+def test_kat_single_isotropic_gaussian_center():
+    """One isotropic Gaussian in front of an axis-aligned camera: analytic alpha profile."""
+    W = H = 32
+    cam = syn.look_at_camera(W, H, azimuth=0.0, elevation=0.0)
+    s = 0.05
+    a = dict(means3D=np.zeros((1, 3), np.float32), scales=np.full((1, 3), s, np.float32),
+             rotations=np.array([[1, 0, 0, 0]], np.float32), opacities=np.array([[0.5]], np.float32))
+    col = np.array([[0.2, 0.4, 0.8]], np.float32)
+    r = run_oracle(a, cam, colors_precomp=col, bg=(0, 0, 0))
+    fx = W / (2 * cam.tanfovx)
+    sigma2 = (fx * s / 4.0) ** 2 + 0.3          # EWA footprint at distance 4 plus the 0.3 low-pass
+    assert r["radii"][0] == math.ceil(3 * math.sqrt(sigma2))
+    assert abs(r["depths"][0] - 4.0) < 1e-5
+    np.testing.assert_allclose(r["means2D"][0], [(W - 1) / 2, (H - 1) / 2], atol=1e-4)
+    ys, xs = np.mgrid[0:H, 0:W]
+    d2 = (xs - (W - 1) / 2) ** 2 + (ys - (H - 1) / 2) ** 2
+    alpha = 0.5 * np.exp(-0.5 * d2 / sigma2)
+    alpha[alpha < 1 / 255] = 0
+    for ch in range(3):
+        np.testing.assert_allclose(r["color"][ch], col[0, ch] * alpha, atol=2e-6)
+    np.testing.assert_allclose(r["depth"][0], 4.0 * alpha, atol=2e-5)
+    np.testing.assert_allclose(r["final_T"], 1 - alpha, atol=1e-6)
+    assert r["num_rendered"] == 4 and list(r["tiles_touched"]) == [4]
+    assert ((r["n_contrib"] == 1) == (alpha > 0)).all()
+
+
+def test_kat_near_plane_cull_and_mark_visible():
+    cam = syn.look_at_camera(32, 32, azimuth=0.0, elevation=0.0)
+    # camera sits at x=+4 looking at the origin: x = 3.9 is 0.1 in front (culled, <= 0.2), x = 3.7 is 0.3 in front
+    pts = np.array([[3.9, 0, 0], [3.7, 0, 0], [5.0, 0, 0], [3.8, 0, 0]], np.float32)
+    a = dict(means3D=pts, scales=np.full((4, 3), 0.01, np.float32), rotations=np.tile([1, 0, 0, 0], (4, 1)).astype(np.float32),
+             opacities=np.full((4, 1), 0.5, np.float32))
+    r = run_oracle(a, cam, colors_precomp=np.ones((4, 3), np.float32))
+    assert r["radii"][0] == 0 and r["radii"][2] == 0 and r["radii"][1] > 0
+    vis = O.mark_visible(pts, cam.viewmatrix, cam.projmatrix)
+    zs = (np.c_[pts, np.ones(4, np.float32)] @ cam.viewmatrix)[:, 2]
+    assert list(vis) == list(zs > np.float32(0.2))
+    assert list(vis)[:3] == [False, True, False]
+
+
+def test_kat_tile_corner_emits_four_keys_y_major_and_tie_order():
+    """A small Gaussian straddling the corner shared by 4 tiles emits keys (y outer, x inner);
+    two Gaussians with identical depth keep ascending index inside each tile (note S)."""
+    W = H = 32
+    cam = syn.look_at_camera(W, H, azimuth=0.0, elevation=0.0)
+    fx = W / (2 * cam.tanfovx)
+    off = 0.5 * 4.0 / fx  # half a pixel: pixel coordinate 15.5 is world offset 0 ... centre is (W-1)/2 = 15.5
+    pts = np.array([[0, 0, 0], [0, 0, 0]], np.float32)
+    a = dict(means3D=pts, scales=np.full((2, 3), 0.02, np.float32), rotations=np.tile([1, 0, 0, 0], (2, 1)).astype(np.float32),
+             opacities=np.full((2, 1), 0.5, np.float32))
+    r = run_oracle(a, cam, colors_precomp=np.ones((2, 3), np.float32))
+    assert list(r["tiles_touched"]) == [4, 4] and list(r["point_offsets"]) == [4, 8]
+    tiles = (r["keys_unsorted"] >> np.uint64(32)).astype(int)
+    assert list(tiles) == [0, 1, 2, 3, 0, 1, 2, 3]
+    assert list(r["values_unsorted"]) == [0, 0, 0, 0, 1, 1, 1, 1]
+    dbits = np.float32(r["depths"][0]).view(np.uint32)
+    assert ((r["keys_unsorted"] & np.uint64(0xFFFFFFFF)) == dbits).all()
+    assert list((r["keys_sorted"] >> np.uint64(32)).astype(int)) == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert list(r["point_list"]) == [0, 1, 0, 1, 0, 1, 0, 1]
+    assert r["ranges"].tolist() == [[0, 2], [2, 4], [4, 6], [6, 8]]
+
+
+def test_empty_and_untouched_tiles():
+    a, cam = small_scene(P=3, W=64, H=48, s0=0.02)
+    r = run_oracle(a, cam)
+    touched = np.zeros(r["ranges"].shape[0], bool)
+    touched[np.unique((r["keys_sorted"] >> np.uint64(32)).astype(int))] = True
+    assert (r["ranges"][~touched] == 0).all()
+    assert (r["ranges"][touched, 1] > r["ranges"][touched, 0]).all()
+    z = O.forward(np.ones(3, np.float32), np.zeros((0, 3), np.float32), None, np.zeros((0, 1), np.float32),
+                  np.zeros((0, 3), np.float32), np.zeros((0, 4), np.float32), 1.0, None, cam.viewmatrix, cam.projmatrix,
+                  cam.tanfovx, cam.tanfovy, 48, 64, np.zeros((0, 16, 3), np.float32), 3, cam.campos)
+    assert z["num_rendered"] == 0 and (z["color"] == 0).all()  # P == 0 skips the launch: rasterize_points.cu:82
+
+
+def test_sort_is_stable_and_sorted():
+    a, cam = small_scene(P=300, W=64, H=48, s0=0.08)
+    a["means3D"][100:200] = a["means3D"][0:100]  # duplicate positions -> identical depth bits
+    r = run_oracle(a, cam)
+    ks, pl = r["keys_sorted"], r["point_list"]
+    assert (np.diff(ks.astype(np.int64)) >= 0).all()
+    same = ks[1:] == ks[:-1]
+    assert same.any() and (pl[1:][same] > pl[:-1][same]).all()
+    order = np.lexsort((r["values_unsorted"], r["keys_unsorted"]))
+    assert (r["keys_unsorted"][order] == ks).all() and (r["values_unsorted"][order] == pl).all()
+
+
+# ---------------------------------------------------------------- float64 autograd cross-check
+
+@pytest.mark.parametrize("deg,seed,maxop", [(3, 0, 1.0), (0, 1, 0.6), (1, 2, 1.0), (2, 3, 0.99)])
+def test_forward_and_backward_match_float64_autograd(deg, seed, maxop):
+    a, cam = small_scene(P=50, W=40, H=24, seed=seed, s0=0.12, max_opacity=maxop)
+    r = run_oracle(a, cam, deg=deg)
+    assert (r["radii"] > 0).sum() > 30
+    cover = cover_masks(r)
+    t = dict(means3D=to64(a["means3D"], True), scales=to64(a["scales"], True), rotations=to64(a["rotations"], True),
+             opacities=to64(a["opacities"][:, 0], True), sh=to64(a["sh"], True))
+    color, depth, T = R64.render64(t["means3D"], t["scales"], t["rotations"], t["opacities"], t["sh"], deg,
+                                   to64(cam.viewmatrix), to64(cam.projmatrix), to64(cam.campos), cam.tanfovx, cam.tanfovy,
+                                   cam.image_height, cam.image_width, torch.ones(3, dtype=torch.float64), cover=cover)
+    ok = torch.from_numpy(r["margin"] > 1e-4)  # pixels whose discrete decisions are not on a knife edge
+    assert ok.float().mean() > 0.99
+    # forward: 1e-5 abs (north_star tolerance)
+    assert (torch.from_numpy(r["color"]).double() - color).abs()[:, ok].max() < 1e-5
+    assert (torch.from_numpy(r["depth"]).double() - depth).abs()[:, ok].max() < 5e-5  # depth ~4: 1e-5 relative
+    assert (torch.from_numpy(r["final_T"]).double() - T).abs()[ok].max() < 1e-5
+    # backward: random upstream gradient, restricted to robust pixels
+    rng = np.random.default_rng(seed)
+    gc = rng.standard_normal(r["color"].shape).astype(np.float32) * ok.numpy()[None]
+    gd = rng.standard_normal(r["depth"].shape).astype(np.float32) * ok.numpy()[None] * 0.1
+    g = O.backward(r, gc, gd)
+    loss = (color * to64(gc)).sum() + (depth * to64(gd)).sum()
+    loss.backward()
+    pairs = [("dL_dmeans3D", t["means3D"].grad), ("dL_dscales", t["scales"].grad), ("dL_drotations", t["rotations"].grad),
+             ("dL_dopacity", t["opacities"].grad[:, None]), ("dL_dsh", t["sh"].grad)]
+    for name, want in pairs:
+        got = torch.from_numpy(g[name]).double()
+        scale = want.abs().max().clamp_min(1e-12)
+        err = (got - want).abs().max() / scale
+        assert err < 1e-4, (name, float(err))  # <= 1e-4 relative (to the tensor's max), north_star tolerance
+
+
+def test_precomputed_color_and_cov_paths_match_float64_autograd():
+    a, cam = small_scene(P=40, W=32, H=32, seed=5, s0=0.15, max_opacity=0.9)
+    r0 = run_oracle(a, cam)
+    cov = r0["cov3D"].copy()
+    col = np.random.default_rng(1).uniform(0, 1, (40, 3)).astype(np.float32)
+    r = run_oracle(a, cam, colors_precomp=col, cov3D_precomp=cov)
+    np.testing.assert_array_equal(r["radii"], r0["radii"])
+    cover = cover_masks(r)
+    tm, tc, tv, to_ = to64(a["means3D"], True), to64(col, True), to64(cov, True), to64(a["opacities"][:, 0], True)
+    color, depth, T = R64.render64(tm, None, None, to_, None, 0, to64(cam.viewmatrix), to64(cam.projmatrix),
+                                   to64(cam.campos), cam.tanfovx, cam.tanfovy, 32, 32, torch.ones(3, dtype=torch.float64),
+                                   colors_precomp=tc, cov3D_precomp=tv, cover=cover)
+    ok = torch.from_numpy(r["margin"] > 1e-4)
+    assert (torch.from_numpy(r["color"]).double() - color).abs()[:, ok].max() < 1e-5
+    gc = np.random.default_rng(2).standard_normal((3, 32, 32)).astype(np.float32) * ok.numpy()[None]
+    g = O.backward(r, gc, np.zeros((1, 32, 32), np.float32))
+    (color * to64(gc)).sum().backward()
+    for name, want in [("dL_dcolors", tc.grad), ("dL_dcov3D", tv.grad), ("dL_dmeans3D", tm.grad), ("dL_dopacity", to_.grad[:, None])]:
+        got = torch.from_numpy(g[name]).double()
+        assert (got - want).abs().max() / want.abs().max() < 1e-4, name
+    assert (g["dL_dsh"].size == 0) and (g["dL_dscales"] == 0).all() and (g["dL_drotations"] == 0).all()
