@@ -1,0 +1,79 @@
+"""ctypes binding of libgs4d.so (include/gs4d.h).  PyTorch is used only for device memory
+and streams; every tensor crosses the boundary as a raw device pointer.
+
+The library must be present: there is NO fallback path.  A missing or unloadable
+libgs4d.so raises at import of the operators that need it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgs4d.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class StateView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "depths", "clamped", "means2D", "cov3D", "conic_opacity", "rgb", "tiles_touched", "point_offsets",
+        "keys_unsorted", "values_unsorted", "keys_sorted", "point_list", "ranges", "final_T", "n_contrib")]
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C 4dgaussians_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU/PyTorch fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.gs4d_last_error.restype = C.c_char_p
+        for name in ("gs4d_geometry_bytes", "gs4d_binning_bytes", "gs4d_image_bytes", "gs4d_backward_scratch_bytes"):
+            getattr(L, name).restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().gs4d_last_error().decode(errors="replace")
+        raise RuntimeError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor, or NULL for None / empty tensors (the reference passes empty
+    CPU tensors for absent inputs, RAST/diff_gaussian_rasterization/__init__.py:198-208)."""
+    if t is None or t.numel() == 0:
+        return C.c_void_p(0)
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class TensorAllocator:
+    """gs4d_alloc_fn backed by a growable uint8 torch tensor (the counterpart of the reference's
+    resizeFunctional lambdas, RAST/rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.error = None
+
+        def _alloc(_ctx, nbytes):
+            try:
+                if self.tensor.numel() < nbytes:
+                    self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+                return self.tensor.data_ptr()
+            except Exception as ex:  # never let an exception cross the C boundary
+                self.error = ex
+                return 0
+
+        self.callback = ALLOC_FN(_alloc)

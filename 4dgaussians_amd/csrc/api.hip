@@ -1,0 +1,276 @@
+// extern "C" entry points of libgs4d.so (see include/gs4d.h) and the scratch-chunk layouts.
+// Host-side orchestration only; the kernels live in the other translation units.
+//
+// Orchestration matched: RAST/cuda_rasterizer/rasterizer_impl.cu:198-339 (forward) and :343-444
+// (backward) of the reference, RAST = submodules/depth-diff-gaussian-rasterization.  Unlike the
+// reference, which launches on the legacy default stream, every launch goes to the stream the
+// caller passes, and no global mutable state is kept (one process per GPU stays independent).
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "gs4d_internal.h"
+
+int gs4d_launch_scan(int P, GeomState& g, int debug, hipStream_t s);
+
+static thread_local char g_err[512] = "";
+
+void gs4d_set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------- chunk layouts
+GeomState GeomState::from_chunk(char*& chunk, size_t P)
+{
+    GeomState g;
+    const size_t nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
+    gs4d_obtain(chunk, g.depths, P);
+    gs4d_obtain(chunk, g.clamped, P * 3);
+    gs4d_obtain(chunk, g.means2D, P);
+    gs4d_obtain(chunk, g.cov3D, P * 6);
+    gs4d_obtain(chunk, g.conic_opacity, P);
+    gs4d_obtain(chunk, g.rgb, P * 3);
+    gs4d_obtain(chunk, g.tiles_touched, P);
+    gs4d_obtain(chunk, g.point_offsets, P);
+    gs4d_obtain(chunk, g.block_sums, nblk);
+    gs4d_obtain(chunk, g.block_offsets, nblk);
+    gs4d_obtain(chunk, g.counters, 64);
+    return g;
+}
+
+size_t GeomState::required(size_t P)
+{
+    char* p = nullptr;
+    GeomState::from_chunk(p, P);
+    return (size_t)p + 256;
+}
+
+ImageState ImageState::from_chunk(char*& chunk, size_t npix, size_t ntiles)
+{
+    ImageState im;
+    gs4d_obtain(chunk, im.final_T, npix);
+    gs4d_obtain(chunk, im.n_contrib, npix);
+    gs4d_obtain(chunk, im.ranges, ntiles);
+    gs4d_obtain(chunk, im.tile_max_contrib, ntiles);
+    return im;
+}
+
+size_t ImageState::required(size_t npix, size_t ntiles)
+{
+    char* p = nullptr;
+    ImageState::from_chunk(p, npix, ntiles);
+    return (size_t)p + 256;
+}
+
+BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes)
+{
+    BinningState b;
+    gs4d_obtain(chunk, b.keys_unsorted, R);
+    gs4d_obtain(chunk, b.values_unsorted, R);
+    gs4d_obtain(chunk, b.keys_tmp[0], R);
+    gs4d_obtain(chunk, b.keys_tmp[1], R);
+    gs4d_obtain(chunk, b.values_tmp[0], R);
+    gs4d_obtain(chunk, b.values_tmp[1], R);
+    gs4d_obtain(chunk, b.inv, R);
+    gs4d_obtain(chunk, b.hist, (size_t)256 * gs4d_sort_blocks(R) + 256);
+    b.sorted = passes > 0 ? (passes - 1) & 1 : 0;
+    return b;
+}
+
+size_t BinningState::required(size_t R)
+{
+    char* p = nullptr;
+    BinningState::from_chunk(p, R, 1);
+    return (size_t)p + 256;
+}
+
+static int sort_passes(int W, int H)
+{
+    const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    return (int)((32 + gs4d_higher_msb((uint32_t)(gx * gy)) + 7) / 8);
+}
+
+extern "C" {
+
+const char* gs4d_last_error(void) { return g_err; }
+int gs4d_abi_version(void) { return 1; }
+
+size_t gs4d_geometry_bytes(int P) { return GeomState::required((size_t)P); }
+size_t gs4d_binning_bytes(int R) { return BinningState::required((size_t)R); }
+size_t gs4d_image_bytes(int width, int height)
+{
+    const size_t gx = (width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    return ImageState::required((size_t)width * height, gx * gy);
+}
+size_t gs4d_backward_scratch_bytes(int R)
+{
+    return gs4d_align_up((size_t)R * GS4D_GRAD_ROW * sizeof(float), 256) + 256 + ((size_t)R / 64 + 64) * sizeof(uint32_t) + 256;
+}
+
+int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
+                           gs4d_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                           int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                           float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug,
+                           void* stream, int* num_rendered)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (num_rendered) *num_rendered = 0;
+    if (P < 0 || width <= 0 || height <= 0 || !geom_alloc || !binning_alloc || !image_alloc) {
+        gs4d_set_error("gs4d_rasterize_forward: bad sizes or missing allocator");
+        return GS4D_EINVAL;
+    }
+    if (P == 0) return GS4D_OK;  // rasterize_points.cu:82
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !cam_pos || !background || !out_color || !out_depth ||
+        !radii) {
+        gs4d_set_error("gs4d_rasterize_forward: null required pointer");
+        return GS4D_EINVAL;
+    }
+    if ((shs == nullptr) == (colors_precomp == nullptr)) {
+        gs4d_set_error("provide exactly one of SHs or precomputed colors");
+        return GS4D_EINVAL;
+    }
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr)) {
+        gs4d_set_error("provide exactly one of scale/rotation pair or precomputed 3D covariance");
+        return GS4D_EINVAL;
+    }
+    if (shs && (M < (D + 1) * (D + 1) || D < 0 || D > 3)) {
+        gs4d_set_error("SH degree %d needs %d coefficients, got M=%d", D, (D + 1) * (D + 1), M);
+        return GS4D_EINVAL;
+    }
+    if (rotations && ((uintptr_t)rotations & 15)) {
+        gs4d_set_error("rotations must be 16-byte aligned");
+        return GS4D_EINVAL;
+    }
+
+    char* chunk = (char*)geom_alloc(geom_ctx, GeomState::required((size_t)P));
+    if (!chunk) { gs4d_set_error("geometry allocator returned NULL"); return GS4D_EALLOC; }
+    GeomState g = GeomState::from_chunk(chunk, (size_t)P);
+
+    const size_t gx = (width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    char* ichunk = (char*)image_alloc(image_ctx, ImageState::required((size_t)width * height, gx * gy));
+    if (!ichunk) { gs4d_set_error("image allocator returned NULL"); return GS4D_EALLOC; }
+    ImageState im = ImageState::from_chunk(ichunk, (size_t)width * height, gx * gy);
+
+    int rc = gs4d_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
+                                    cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height,
+                                    tan_fovx, tan_fovy, prefiltered, radii, g, debug, s);
+    if (rc) return rc;
+    rc = gs4d_launch_scan(P, g, debug, s);
+    if (rc) return rc;
+
+    // one host sync to size the binning chunk (rasterizer_impl.cu:282)
+    uint32_t host_counters[2] = {0, 0};
+    GS4D_HIP_CHECK(hipMemcpyAsync(host_counters, g.counters, sizeof host_counters, hipMemcpyDeviceToHost, s));
+    GS4D_HIP_CHECK(hipStreamSynchronize(s));
+    if (host_counters[1]) {
+        gs4d_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
+        return GS4D_EPREFILTER;
+    }
+    if (host_counters[0] > 0x7fffffffu) {
+        gs4d_set_error("num_rendered %u overflows int", host_counters[0]);
+        return GS4D_EINVAL;
+    }
+    const int R = (int)host_counters[0];
+    if (num_rendered) *num_rendered = R;
+
+    char* bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R));
+    if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
+    BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
+
+    rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);
+    if (rc) return rc;
+    const float* features = colors_precomp ? colors_precomp : g.rgb;
+    return gs4d_launch_blend_forward(width, height, g, b, im, features, background, out_color, out_depth, debug, s);
+}
+
+int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                            const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                            const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                            float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                            void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return GS4D_OK;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0 || !scratch_alloc || !geom_buffer || !img_buffer ||
+        (R > 0 && !binning_buffer) || !dL_dpix || !dL_dpix_depth || !means3D || !radii) {
+        gs4d_set_error("gs4d_rasterize_backward: bad sizes or null pointer");
+        return GS4D_EINVAL;
+    }
+    if (rotations && (((uintptr_t)rotations & 15) || ((uintptr_t)dL_drot & 15))) {
+        gs4d_set_error("rotations / dL_drot must be 16-byte aligned");
+        return GS4D_EINVAL;
+    }
+    if (R == 0) return GS4D_OK;  // nothing was rendered: every gradient stays zero
+    char* chunk = geom_buffer;
+    GeomState g = GeomState::from_chunk(chunk, (size_t)P);
+    const size_t gx = (width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    char* ichunk = img_buffer;
+    ImageState im = ImageState::from_chunk(ichunk, (size_t)width * height, gx * gy);
+    char* bchunk = binning_buffer;
+    BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
+
+    float* inst_grad = (float*)scratch_alloc(scratch_ctx, gs4d_backward_scratch_bytes(R));
+    if (!inst_grad) { gs4d_set_error("backward scratch allocator returned NULL"); return GS4D_EALLOC; }
+    if ((uintptr_t)inst_grad & 255) { gs4d_set_error("backward scratch must be 256-byte aligned"); return GS4D_EINVAL; }
+
+    const float* features = colors_precomp ? colors_precomp : g.rgb;
+    int rc = gs4d_launch_blend_backward(width, height, R, g, b, im, features, background, dL_dpix, dL_dpix_depth,
+                                        inst_grad, debug, s);
+    if (rc) return rc;
+    const float* cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
+    return gs4d_launch_geom_backward(P, D, M, R, width, height, means3D, radii, shs, scales, rotations,
+                                     scale_modifier, cov3D, viewmatrix, projmatrix, tan_fovx, tan_fovy, campos, g, b,
+                                     inst_grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
+                                     dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, s);
+}
+
+int gs4d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, void* stream)
+{
+    (void)projmatrix;
+    if (P == 0) return GS4D_OK;
+    if (P < 0 || !means3D || !viewmatrix || !present) {
+        gs4d_set_error("gs4d_mark_visible: bad arguments");
+        return GS4D_EINVAL;
+    }
+    return gs4d_launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+}
+
+int gs4d_state_view_get(int P, int R, int width, int height, char* geom_buffer, char* binning_buffer,
+                        char* img_buffer, gs4d_state_view* out)
+{
+    if (!out || !geom_buffer || !img_buffer || P < 0 || R < 0) {
+        gs4d_set_error("gs4d_state_view_get: bad arguments");
+        return GS4D_EINVAL;
+    }
+    char* c = geom_buffer;
+    GeomState g = GeomState::from_chunk(c, (size_t)P);
+    const size_t gx = (width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    c = img_buffer;
+    ImageState im = ImageState::from_chunk(c, (size_t)width * height, gx * gy);
+    out->depths = g.depths; out->clamped = g.clamped; out->means2D = (const float*)g.means2D; out->cov3D = g.cov3D;
+    out->conic_opacity = (const float*)g.conic_opacity; out->rgb = g.rgb; out->tiles_touched = g.tiles_touched;
+    out->point_offsets = g.point_offsets;
+    out->ranges = (const uint32_t*)im.ranges; out->final_T = im.final_T; out->n_contrib = im.n_contrib;
+    out->keys_unsorted = nullptr; out->values_unsorted = nullptr; out->keys_sorted = nullptr; out->point_list = nullptr;
+    if (binning_buffer && R > 0) {
+        c = binning_buffer;
+        BinningState b = BinningState::from_chunk(c, (size_t)R, sort_passes(width, height));
+        out->keys_unsorted = b.keys_unsorted; out->values_unsorted = b.values_unsorted;
+        out->keys_sorted = b.keys_sorted(); out->point_list = b.point_list();
+    }
+    return GS4D_OK;
+}
+
+}  // extern "C"

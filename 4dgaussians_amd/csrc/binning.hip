@@ -1,0 +1,375 @@
+// Binning stage for gfx950: instance-offset scan, balanced tile-key emission, stable LSD radix
+// sort of (tile | depth) keys with wave-level match ranking in LDS, and tile ranges.
+//
+// Behaviour matched (reference, RAST = submodules/depth-diff-gaussian-rasterization):
+//   RAST/cuda_rasterizer/rasterizer_impl.cu:278     inclusive scan of tiles_touched
+//   RAST/cuda_rasterizer/rasterizer_impl.cu:70-111  duplicateWithKeys (key = tile<<32 | depth bits, y outer / x inner)
+//   RAST/cuda_rasterizer/rasterizer_impl.cu:301-309 stable radix sort on the low 32+bit key bits
+//   RAST/cuda_rasterizer/rasterizer_impl.cu:311,116-138 zeroed ranges + identifyTileRanges
+// All outputs here are integers and must be bit-exact against the oracle.
+#include "gs4d_internal.h"
+#include "gs4d_math.h"
+
+using namespace gs4d;
+
+namespace {
+
+// ------------------------------------------------------------------ block-sum scan (1 workgroup)
+// block_offsets = exclusive scan of block_sums; counters[0] = total.  n is ceil(P/256)
+// (391 at P = 100k, 19.5k at P = 5M), so one 1024-lane workgroup looping over chunks is enough.
+__global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ block_sums,
+                                                               uint32_t* __restrict__ block_offsets,
+                                                               uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + threadIdx.x;
+        const uint32_t v = i < n ? block_sums[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+        for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
+        const uint32_t carry = s_carry;
+        if (i < n) block_offsets[i] = carry + wave_prefix + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) counters[0] = s_carry;
+}
+
+// ------------------------------------------------------------------ key emission
+// One workgroup per 256 consecutive Gaussians.  The workgroup scans its 256 tile counts in LDS
+// (giving point_offsets for free) and then walks its output slots with all 256 lanes: slot s is
+// mapped back to its Gaussian by a binary search over the LDS offsets, so a Gaussian that covers
+// thousands of tiles costs the same per slot as one that covers four, and every store is
+// coalesced.  Emission order inside a Gaussian is y outer, x inner, as the reference.
+__global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
+    int P, int gx, int gy, const float2* __restrict__ means2D, const float* __restrict__ depths,
+    const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
+    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ point_offsets,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ values)
+{
+    __shared__ uint32_t s_incl[GS4D_PRE_BLOCK];   // inclusive scan of counts inside the workgroup
+    __shared__ uint32_t s_wave[GS4D_PRE_BLOCK / 64];
+    __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
+    __shared__ uint32_t s_depth[GS4D_PRE_BLOCK];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * GS4D_PRE_BLOCK + tid;
+    uint32_t cnt = 0;
+    if (idx < P) {
+        cnt = tiles_touched[idx];
+        if (cnt) {
+            const float2 m = means2D[idx];
+            int x0, y0, x1, y1;
+            tile_rect(m.x, m.y, radii[idx], gx, gy, x0, y0, x1, y1);
+            s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
+            s_depth[tid] = __float_as_uint(depths[idx]);
+        }
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_prefix = 0;
+    for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
+    incl += wave_prefix;
+    s_incl[tid] = incl;
+    const uint32_t base = block_offsets[blockIdx.x];
+    if (idx < P) point_offsets[idx] = base + incl;
+    __syncthreads();
+
+    const uint32_t total = s_incl[GS4D_PRE_BLOCK - 1];
+    for (uint32_t s = tid; s < total; s += GS4D_PRE_BLOCK) {
+        // first g with s_incl[g] > s
+        int lo = 0, hi = GS4D_PRE_BLOCK - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (s_incl[mid] > s) hi = mid; else lo = mid + 1;
+        }
+        const int g = lo;
+        const uint32_t excl = g ? s_incl[g - 1] : 0u;
+        const uint32_t k = s - excl;
+        const int w = s_w[g];
+        const int ty = s_y0[g] + (int)(k / (uint32_t)w);
+        const int tx = s_x0[g] + (int)(k % (uint32_t)w);
+        const uint64_t key = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | (uint64_t)s_depth[g];
+        keys[base + s] = key;
+        values[base + s] = (uint32_t)(blockIdx.x * GS4D_PRE_BLOCK + g);
+    }
+}
+
+// ------------------------------------------------------------------ radix sort, one 8-bit digit per pass
+// Pass structure (all kernels on one stream, no inter-workgroup communication inside a launch):
+//   sort_hist_kernel    : per-tile 256-bin digit histogram -> hist[digit][tile]
+//   sort_scan_kernel    : workgroup d scans row d of hist in place (exclusive) and writes the row total
+//   sort_scatter_kernel : re-reads its tile, ranks keys stably (wave-level match + per-wave LDS
+//                         counters), stages the tile sorted by digit in LDS and writes runs out.
+// A tile is 2048 keys: wave w owns keys [512w, 512w+512), lane l handles key 512w + 64r + l in
+// round r, so (wave, round, lane) order == memory order, which is what makes the sort stable.
+
+__global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_hist_kernel(uint32_t R, int shift,
+                                                                      const uint64_t* __restrict__ keys,
+                                                                      uint32_t* __restrict__ hist, uint32_t ntiles)
+{
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * GS4D_SORT_TILE;
+#pragma unroll
+    for (int i = 0; i < GS4D_SORT_ITEMS; i++) {
+        const uint32_t k = base + i * GS4D_SORT_THREADS + threadIdx.x;
+        if (k < R) atomicAdd(&s_h[(uint32_t)(keys[k] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = s_h[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t ntiles, uint32_t* __restrict__ hist,
+                                                        uint32_t* __restrict__ digit_totals)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    uint32_t* row = hist + (size_t)blockIdx.x * ntiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < ntiles; b += 256) {
+        const uint32_t i = b + threadIdx.x;
+        const uint32_t v = i < ntiles ? row[i] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wp = 0;
+        for (int w = 0; w < wave; w++) wp += s_wave[w];
+        const uint32_t carry = s_carry;
+        if (i < ntiles) row[i] = carry + wp + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = carry + wp + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) digit_totals[blockIdx.x] = s_carry;
+}
+
+__global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_scatter_kernel(
+    uint32_t R, int shift, const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ hist,
+    const uint32_t* __restrict__ digit_totals, uint32_t ntiles)
+{
+    __shared__ uint32_t s_cnt[4][256];        // per-wave digit counts -> exclusive offsets inside the tile
+    __shared__ uint32_t s_digit_start[256];   // first staged slot of each digit inside the tile
+    __shared__ uint32_t s_global[256];        // global output position of that first slot
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint64_t s_keys[GS4D_SORT_TILE];
+    __shared__ uint32_t s_vals[GS4D_SORT_TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 4 * 256; i += GS4D_SORT_THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t tile_base = blockIdx.x * GS4D_SORT_TILE;
+    const uint32_t wave_base = tile_base + wave * (64 * GS4D_SORT_ITEMS);
+    uint64_t key[GS4D_SORT_ITEMS];
+    uint32_t val[GS4D_SORT_ITEMS];
+    uint32_t rank[GS4D_SORT_ITEMS];   // rank among equal digits inside this wave's 512 keys
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < GS4D_SORT_ITEMS; r++) {
+        const uint32_t k = wave_base + r * 64 + lane;
+        const bool valid = k < R;
+        key[r] = valid ? keys_in[k] : ~0ull;
+        val[r] = valid ? vals_in[k] : 0u;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+        // lanes holding the same digit (invalid lanes form their own group via bit 8)
+        uint64_t same = __ballot(valid) ^ (valid ? 0ull : ~0ull);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & lanemask_lt);
+        const int leader = __ffsll((unsigned long long)same) - 1;
+        uint32_t prev = 0;
+        if (valid && lane == leader) {
+            prev = s_cnt[wave][d];
+            s_cnt[wave][d] = prev + (uint32_t)__popcll(same);
+        }
+        prev = __shfl(prev, leader, 64);
+        rank[r] = prev + before;
+    }
+    __syncthreads();
+
+    // per digit: exclusive offsets across the 4 waves, tile total, and exclusive scan over digits
+    {
+        const uint32_t c0 = s_cnt[0][tid], c1 = s_cnt[1][tid], c2 = s_cnt[2][tid], c3 = s_cnt[3][tid];
+        s_cnt[0][tid] = 0; s_cnt[1][tid] = c0; s_cnt[2][tid] = c0 + c1; s_cnt[3][tid] = c0 + c1 + c2;
+        const uint32_t total = c0 + c1 + c2 + c3;
+        uint32_t incl = total;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wp = 0;
+        for (int w = 0; w < wave; w++) wp += s_wave[w];
+        s_digit_start[tid] = wp + incl - total;
+        // global position = (keys with a smaller digit anywhere) + (same digit in earlier tiles)
+        uint32_t smaller = 0;
+        // exclusive scan of the 256 digit totals, recomputed per workgroup (256 adds per lane worst case
+        // would be wasteful; do it with the same wave-scan)
+        const uint32_t dt = digit_totals[tid];
+        uint32_t dincl = dt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(dincl, off, 64);
+            if (lane >= off) dincl += t;
+        }
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = dincl;
+        __syncthreads();
+        for (int w = 0; w < wave; w++) smaller += s_wave[w];
+        smaller += dincl - dt;
+        s_global[tid] = smaller + hist[(size_t)tid * ntiles + blockIdx.x];
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < GS4D_SORT_ITEMS; r++) {
+        const uint32_t k = wave_base + r * 64 + lane;
+        if (k < R) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t slot = s_digit_start[d] + s_cnt[wave][d] + rank[r];
+            s_keys[slot] = key[r];
+            s_vals[slot] = val[r];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t n_valid = min((uint32_t)GS4D_SORT_TILE, R - tile_base);
+    for (uint32_t i = tid; i < n_valid; i += GS4D_SORT_THREADS) {
+        const uint64_t kk = s_keys[i];
+        const uint32_t d = (uint32_t)(kk >> shift) & 255u;
+        const uint32_t dst = s_global[d] + (i - s_digit_start[d]);
+        keys_out[dst] = kk;
+        vals_out[dst] = s_vals[i];
+    }
+}
+
+// ------------------------------------------------------------------ tile ranges + inverse permutation
+// ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand); inv[emission slot] = sorted
+// position, recovered from the key's tile id and the Gaussian's rectangle (no extra sort payload).
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, int gx, int gy,
+                                                          const uint64_t* __restrict__ keys_sorted,
+                                                          const uint32_t* __restrict__ point_list,
+                                                          const float2* __restrict__ means2D,
+                                                          const int* __restrict__ radii,
+                                                          const uint32_t* __restrict__ point_offsets,
+                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ inv)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R) return;
+    const uint32_t tile = (uint32_t)(keys_sorted[idx] >> 32);
+    if (idx == 0)
+        ranges[tile].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys_sorted[idx - 1] >> 32);
+        if (tile != prev) {
+            ranges[prev].y = idx;
+            ranges[tile].x = idx;
+        }
+    }
+    if (idx == R - 1) ranges[tile].y = R;
+
+    const uint32_t g = point_list[idx];
+    const float2 m = means2D[g];
+    int x0, y0, x1, y1;
+    tile_rect(m.x, m.y, radii[g], gx, gy, x0, y0, x1, y1);
+    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile % (uint32_t)gx);
+    const uint32_t first = g ? point_offsets[g - 1] : 0u;
+    inv[first + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0))] = idx;
+}
+
+}  // namespace
+
+// Stable LSD radix sort of (u64 key, u32 value) pairs on the low 8*passes key bits.  The input
+// arrays are left intact; the result lands in keys_tmp[*where] / vals_tmp[*where].
+// hist must hold 256 * gs4d_sort_blocks(R) + 256 words.
+int gs4d_radix_sort_pairs(uint32_t R, int passes, const uint64_t* keys_in, const uint32_t* vals_in,
+                          uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
+                          int debug, hipStream_t s)
+{
+    const uint32_t ntiles = gs4d_sort_blocks((size_t)R);
+    uint32_t* digit_totals = hist + (size_t)256 * ntiles;
+    const uint64_t* kin = keys_in;
+    const uint32_t* vin = vals_in;
+    *where = 0;
+    for (int p = 0; p < passes; p++) {
+        uint64_t* kout = keys_tmp[p & 1];
+        uint32_t* vout = vals_tmp[p & 1];
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, 8 * p, kin, hist, ntiles);
+        hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(256), 0, s, ntiles, hist, digit_totals);
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, 8 * p, kin, vin, kout,
+                           vout, hist, digit_totals, ntiles);
+        GS4D_LAUNCH_CHECK("radix_sort_pass", debug, s);
+        kin = kout;
+        vin = vout;
+        *where = p & 1;
+    }
+    return GS4D_OK;
+}
+
+int gs4d_launch_scan(int P, GeomState& g, int debug, hipStream_t s)
+{
+    const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.block_offsets,
+                       g.counters);
+    GS4D_LAUNCH_CHECK("scan_block_sums", debug, s);
+    return GS4D_OK;
+}
+
+int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
+                        int debug, hipStream_t s)
+{
+    const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
+    hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
+                       radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted);
+    GS4D_LAUNCH_CHECK("emit_keys", debug, s);
+
+    GS4D_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
+    if (R <= 0) return GS4D_OK;
+
+    const uint32_t bits = 32 + gs4d_higher_msb((uint32_t)(gx * gy));
+    const int passes = (int)((bits + 7) / 8);
+    int where = 0;
+    int rc = gs4d_radix_sort_pairs((uint32_t)R, passes, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
+                                   b.hist, &where, debug, s);
+    if (rc) return rc;
+    b.sorted = where;
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
+                       b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, im.ranges, b.inv);
+    GS4D_LAUNCH_CHECK("tile_ranges", debug, s);
+    return GS4D_OK;
+}

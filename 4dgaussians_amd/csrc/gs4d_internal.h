@@ -1,0 +1,125 @@
+// Internal definitions shared by the HIP translation units of libgs4d.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/gs4d.h"
+
+#define GS4D_TILE_X 16
+#define GS4D_TILE_Y 16
+#define GS4D_TILE_PIX (GS4D_TILE_X * GS4D_TILE_Y)
+#define GS4D_PRE_BLOCK 256          // Gaussians per preprocess / emit workgroup
+#define GS4D_GRAD_ROW 12            // floats per per-instance gradient row (10 used, padded to 48 B)
+
+void gs4d_set_error(const char* fmt, ...);
+
+#define GS4D_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            gs4d_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return GS4D_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+#define GS4D_LAUNCH_CHECK(name, debug, stream)                                            \
+    do {                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                \
+        if (e_ == hipSuccess && (debug)) e_ = hipStreamSynchronize(stream);               \
+        if (e_ != hipSuccess) {                                                           \
+            gs4d_set_error("kernel %s failed: %s", name, hipGetErrorString(e_));          \
+            return GS4D_EHIP;                                                             \
+        }                                                                                 \
+    } while (0)
+
+static inline size_t gs4d_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <typename T>
+static inline void gs4d_obtain(char*& chunk, T*& ptr, size_t count)
+{
+    size_t off = gs4d_align_up((size_t)chunk, 256);
+    ptr = (T*)off;
+    chunk = (char*)(ptr + count);
+}
+
+// ---- scratch layouts (opaque to callers; see gs4d_state_view_get) ----
+struct GeomState {
+    float* depths;            // [P] view-space z
+    uint8_t* clamped;         // [P,3]
+    float2* means2D;          // [P]
+    float* cov3D;             // [P,6]
+    float4* conic_opacity;    // [P]
+    float* rgb;               // [P,3]
+    uint32_t* tiles_touched;  // [P]
+    uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched
+    uint32_t* block_sums;     // [ceil(P/256)]
+    uint32_t* block_offsets;  // [ceil(P/256)] exclusive scan of block_sums
+    uint32_t* counters;       // [64] counters[0] = num_rendered, counters[1] = prefilter violation flag
+    static GeomState from_chunk(char*& chunk, size_t P);
+    static size_t required(size_t P);
+};
+
+struct ImageState {
+    float* final_T;           // [H*W]
+    uint32_t* n_contrib;      // [H*W]
+    uint2* ranges;            // [tiles]
+    uint32_t* tile_max_contrib; // [tiles] max n_contrib over the tile's pixels (written by the forward blend)
+    static ImageState from_chunk(char*& chunk, size_t npix, size_t ntiles);
+    static size_t required(size_t npix, size_t ntiles);
+};
+
+struct BinningState {
+    uint64_t* keys_unsorted;  // [R] emission order (kept intact for gs4d_state_view_get)
+    uint32_t* values_unsorted;
+    uint64_t* keys_tmp[2];    // radix-sort ping-pong
+    uint32_t* values_tmp[2];
+    uint32_t* inv;            // [R] sorted position of emission slot s (built with the tile ranges)
+    uint32_t* hist;           // sort scratch: [256 digits][sort blocks] + [256] digit totals
+    int sorted;               // which ping-pong half holds the sorted lists after `passes` passes
+    uint64_t* keys_sorted() const { return keys_tmp[sorted]; }
+    uint32_t* point_list() const { return values_tmp[sorted]; }
+    static BinningState from_chunk(char*& chunk, size_t R, int passes);
+    static size_t required(size_t R);
+};
+
+// sort tile geometry
+#define GS4D_SORT_THREADS 256
+#define GS4D_SORT_ITEMS 8
+#define GS4D_SORT_TILE (GS4D_SORT_THREADS * GS4D_SORT_ITEMS)
+static inline uint32_t gs4d_sort_blocks(size_t R) { return (uint32_t)((R + GS4D_SORT_TILE - 1) / GS4D_SORT_TILE); }
+
+// rasterizer_impl.cu:35-50 semantics: number of bits needed for n
+static inline uint32_t gs4d_higher_msb(uint32_t n)
+{
+    uint32_t b = 0;
+    while (b < 32 && (n >> b)) b++;
+    return b == 0 ? 1 : b;
+}
+
+int gs4d_radix_sort_pairs(uint32_t R, int passes, const uint64_t* keys_in, const uint32_t* vals_in,
+                          uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
+                          int debug, hipStream_t s);
+
+// ---- stage launchers (each returns GS4D_OK or an error) ----
+int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
+                           const float* rotations, const float* opacities, const float* shs,
+                           const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
+                           const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
+                           float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s);
+int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
+                        int debug, hipStream_t s);
+int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
+                              const float* features, const float* bg, float* out_color, float* out_depth, int debug,
+                              hipStream_t s);
+int gs4d_launch_blend_backward(int W, int H, int R, const GeomState& g, const BinningState& b, const ImageState& im,
+                               const float* features, const float* bg, const float* dL_dpix,
+                               const float* dL_dpix_depth, float* inst_grad, int debug, hipStream_t s);
+int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const float* means3D, const int* radii,
+                              const float* shs, const float* scales, const float* rotations, float scale_modifier,
+                              const float* cov3D, const float* viewmatrix, const float* projmatrix,
+                              float tan_fovx, float tan_fovy, const float* campos, const GeomState& g,
+                              const BinningState& b, const float* inst_grad, float* dL_dmean2D, float* dL_dconic,
+                              float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                              float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                              hipStream_t s);

@@ -1,0 +1,147 @@
+// Device-side float32 math for the per-Gaussian kernels.  Translation units that include
+// this header are compiled with -ffp-contract=off: radii, tile rectangles and sort keys are
+// integers decided by float32 arithmetic, and the parity contract is bit-exactness
+// against an un-contracted IEEE evaluation in a fixed operation order.
+//
+// Behaviour being matched (reference, RAST = submodules/depth-diff-gaussian-rasterization):
+//   RAST/cuda_rasterizer/auxiliary.h:22-132   constants, ndc2Pix, getRect, transforms, dnormvdv
+//   RAST/third_party/glm                      column-major mat3, product order of type_mat3x3.inl:486-519
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gs4d {
+
+__device__ __constant__ const float kSH_C0 = 0.28209479177387814f;
+__device__ __constant__ const float kSH_C1 = 0.4886025119029199f;
+__device__ __constant__ const float kSH_C2[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                                  -1.0925484305920792f, 0.5462742152960396f};
+__device__ __constant__ const float kSH_C3[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                                  0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                                  -0.5900435899266435f};
+
+// Column-major 3x3: e[c][r] is column c, row r.
+struct Mat3 {
+    float e[3][3];
+};
+
+__device__ __forceinline__ Mat3 mat3_from_columns(float a, float b, float c, float d, float e, float f, float g,
+                                                  float h, float i)
+{
+    Mat3 m;
+    m.e[0][0] = a; m.e[0][1] = b; m.e[0][2] = c;
+    m.e[1][0] = d; m.e[1][1] = e; m.e[1][2] = f;
+    m.e[2][0] = g; m.e[2][1] = h; m.e[2][2] = i;
+    return m;
+}
+
+// out[c][r] = A[0][r]*B[c][0] + A[1][r]*B[c][1] + A[2][r]*B[c][2], summed left to right.
+__device__ __forceinline__ Mat3 mat3_product(const Mat3& A, const Mat3& B)
+{
+    Mat3 o;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+            o.e[c][r] = A.e[0][r] * B.e[c][0] + A.e[1][r] * B.e[c][1] + A.e[2][r] * B.e[c][2];
+    return o;
+}
+
+__device__ __forceinline__ Mat3 mat3_transposed(const Mat3& A)
+{
+    Mat3 o;
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int r = 0; r < 3; r++) o.e[c][r] = A.e[r][c];
+    return o;
+}
+
+// The matrices arrive as 16 floats of a transposed 4x4 (scene/cameras.py:103-105), so element
+// [k*4 + j] multiplies input coordinate k and feeds output coordinate j.
+__device__ __forceinline__ float3 affine_point(const float3 p, const float* __restrict__ m)
+{
+    float3 o;
+    o.x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+    o.y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+    o.z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+    return o;
+}
+
+__device__ __forceinline__ float4 projective_point(const float3 p, const float* __restrict__ m)
+{
+    float4 o;
+    o.x = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+    o.y = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+    o.z = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+    o.w = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
+    return o;
+}
+
+// NDC -> pixel centre, evaluated in double then narrowed (auxiliary.h:41-44 uses double literals).
+__device__ __forceinline__ float ndc_to_pixel(float v, int S)
+{
+    return (float)(((v + 1.0) * S - 1.0) * 0.5);
+}
+
+// Tile rectangle [lo, hi) of a disc of integer radius around p, clamped to the tile grid
+// (auxiliary.h:46-56).  float -> int conversion saturates on this hardware (v_cvt_i32_f32).
+__device__ __forceinline__ void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0,
+                                          int& x1, int& y1)
+{
+    x0 = min(gx, max(0, (int)((px - radius) / GS4D_TILE_X)));
+    y0 = min(gy, max(0, (int)((py - radius) / GS4D_TILE_Y)));
+    x1 = min(gx, max(0, (int)((px + radius + GS4D_TILE_X - 1) / GS4D_TILE_X)));
+    y1 = min(gy, max(0, (int)((py + radius + GS4D_TILE_Y - 1) / GS4D_TILE_Y)));
+}
+
+// Everything the EWA projection needs in both directions: clamped view-space mean t, the
+// un-clamped ratios, T = W*J, the symmetric world covariance as a matrix, W, and cov2D
+// before the 0.3 low-pass (forward.cu:74-106 / backward.cu:166-194).
+struct Ewa {
+    float3 t;
+    float txtz, tytz;
+    Mat3 T, V, Wm, cov;
+};
+
+__device__ __forceinline__ Ewa ewa_project(const float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                           const float* __restrict__ c3, const float* __restrict__ view)
+{
+    Ewa o;
+    float3 t = affine_point(mean, view);
+    const float limx = 1.3f * tan_fovx;
+    const float limy = 1.3f * tan_fovy;
+    o.txtz = t.x / t.z;
+    o.tytz = t.y / t.z;
+    t.x = fminf(limx, fmaxf(-limx, o.txtz)) * t.z;
+    t.y = fminf(limy, fmaxf(-limy, o.tytz)) * t.z;
+    o.t = t;
+    const Mat3 J = mat3_from_columns(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z),
+                                     0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z),
+                                     0.0f, 0.0f, 0.0f);
+    o.Wm = mat3_from_columns(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    o.T = mat3_product(o.Wm, J);
+    o.V = mat3_from_columns(c3[0], c3[1], c3[2], c3[1], c3[3], c3[4], c3[2], c3[4], c3[5]);
+    const Mat3 Tt = mat3_transposed(o.T);
+    const Mat3 Vt = mat3_transposed(o.V);
+    const Mat3 tmp = mat3_product(Tt, Vt);
+    o.cov = mat3_product(tmp, o.T);
+    return o;
+}
+
+// Rotation matrix columns from the (r,x,y,z) quaternion, NOT normalised (forward.cu:127).
+__device__ __forceinline__ Mat3 quat_columns(const float4 q)
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    return mat3_from_columns(
+        1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+        2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+        2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+}
+
+__device__ __forceinline__ Mat3 scale_columns(const float3 s)
+{
+    return mat3_from_columns(s.x, 0.f, 0.f, 0.f, s.y, 0.f, 0.f, 0.f, s.z);
+}
+
+}  // namespace gs4d

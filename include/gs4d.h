@@ -1,0 +1,157 @@
+/*
+ * gs4d.h -- C ABI of libgs4d.so, the MI355X (gfx950) renderer for the 4D-Gaussian-Splatting
+ * render path.  Plain pointers and sizes only (no torch types); every pointer marked
+ * "device" is HIP device memory on the current device; `stream` is a hipStream_t passed
+ * as void* (NULL = the default stream).  Every function returns 0 on success or a negative
+ * GS4D_E* code; gs4d_last_error() returns a thread-local description of the last failure.
+ *
+ * The entry points mirror, one to one, the C++ API that the reference's torch glue binds
+ * (paths relative to the reference repo; RAST = submodules/depth-diff-gaussian-rasterization):
+ *
+ *   gs4d_rasterize_forward    <->  CudaRasterizer::Rasterizer::forward     RAST/cuda_rasterizer/rasterizer.h:31-54
+ *   gs4d_rasterize_backward   <->  CudaRasterizer::Rasterizer::backward    RAST/cuda_rasterizer/rasterizer.h:56-87
+ *   gs4d_mark_visible         <->  CudaRasterizer::Rasterizer::markVisible RAST/cuda_rasterizer/rasterizer.h:24-29
+ *   gs4d_knn_mean_dist2       <->  SimpleKNN::knn                          submodules/simple-knn/simple_knn.h:15-19
+ *   gs4d_alloc_fn             <->  std::function<char*(size_t)> resize lambdas, RAST/rasterize_points.cu:27-33
+ *   gs4d_hexplane_*           <->  HexPlaneField.get_density / interpolate_ms_features, scene/hexplane.py:100-131,192-215
+ *   gs4d_deform_mlp_*         <->  Deformation.query_time_force trunk + heads, scene/deformation.py:128-200
+ *
+ * The scratch buffers (geometry / binning / image) are opaque byte chunks owned by the
+ * caller exactly as in the reference (they are only round-tripped from forward to
+ * backward); gs4d_state_view() exposes the arrays inside them for bit-exact checks.
+ */
+#ifndef GS4D_H_INCLUDED
+#define GS4D_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GS4D_OK 0
+#define GS4D_EINVAL (-1)   /* bad argument (shape / null pointer / unsupported combination) */
+#define GS4D_EHIP (-2)     /* a HIP runtime call or kernel launch failed */
+#define GS4D_EALLOC (-3)   /* the caller's allocator returned NULL */
+#define GS4D_EPREFILTER (-4) /* `prefiltered` was set but a Gaussian failed the near-plane test (reference: device trap, auxiliary.h:156-160) */
+
+/* Caller-provided scratch allocator: must return device memory of at least `bytes` bytes
+ * (256-byte aligned) that stays valid until the caller releases it. */
+typedef void* (*gs4d_alloc_fn)(void* ctx, size_t bytes);
+
+const char* gs4d_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int gs4d_abi_version(void);
+
+/*
+ * Forward render.  Replaces Rasterizer::forward (rasterizer.h:31-54; implementation
+ * rasterizer_impl.cu:198-339).  Argument meaning is identical:
+ *   P Gaussians, D active SH degree, M SH coefficients per Gaussian (0 if shs == NULL);
+ *   exactly one of (shs, colors_precomp) and one of ((scales, rotations), cov3D_precomp)
+ *   is non-NULL; viewmatrix / projmatrix are the 16-float transposed matrices of
+ *   scene/cameras.py:103-105.  out_color [3,H,W], out_depth [1,H,W] and radii [P] must be
+ *   zero-initialised by the caller (rasterize_points.cu:68-70).
+ * *num_rendered receives the number of (Gaussian, tile) instances.  One host
+ * synchronisation on `stream` happens inside (to size the binning buffer), as in
+ * rasterizer_impl.cu:282.
+ */
+int gs4d_rasterize_forward(
+    gs4d_alloc_fn geom_alloc, void* geom_ctx,
+    gs4d_alloc_fn binning_alloc, void* binning_ctx,
+    gs4d_alloc_fn image_alloc, void* image_ctx,
+    int P, int D, int M,
+    const float* background,          /* device [3] */
+    int width, int height,
+    const float* means3D,             /* device [P,3] */
+    const float* shs,                 /* device [P,M,3] or NULL */
+    const float* colors_precomp,      /* device [P,3] or NULL */
+    const float* opacities,           /* device [P] */
+    const float* scales,              /* device [P,3] or NULL */
+    float scale_modifier,
+    const float* rotations,           /* device [P,4] or NULL */
+    const float* cov3D_precomp,       /* device [P,6] or NULL */
+    const float* viewmatrix,          /* device [16] */
+    const float* projmatrix,          /* device [16] */
+    const float* cam_pos,             /* device [3] */
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    float* out_color, float* out_depth, int* radii,
+    int debug,
+    void* stream,
+    int* num_rendered);
+
+/*
+ * Backward.  Replaces Rasterizer::backward (rasterizer.h:56-87; rasterizer_impl.cu:343-444).
+ * R is the num_rendered the forward returned; geom/binning/img buffers are the chunks the
+ * forward filled.  All dL_d* outputs must be zero-initialised by the caller
+ * (rasterize_points.cu:154-163): dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P],
+ * dL_dcolor [P,3], dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3],
+ * dL_dscale [P,3], dL_drot [P,4].
+ * `scratch_alloc` provides the per-instance gradient rows (48 bytes x R) that replace the
+ * reference's per-pixel global atomics; results are bitwise reproducible run to run.
+ */
+int gs4d_rasterize_backward(
+    gs4d_alloc_fn scratch_alloc, void* scratch_ctx,
+    int P, int D, int M, int R,
+    const float* background, int width, int height,
+    const float* means3D, const float* shs, const float* colors_precomp,
+    const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+    const float* viewmatrix, const float* projmatrix, const float* campos,
+    float tan_fovx, float tan_fovy,
+    const int* radii,
+    char* geom_buffer, char* binning_buffer, char* img_buffer,
+    const float* dL_dpix,             /* device [3,H,W] */
+    const float* dL_dpix_depth,       /* device [1,H,W] */
+    float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_ddepth,
+    float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
+    int debug,
+    void* stream);
+
+/* present[i] = (view-space z of means3D[i]) > 0.2 ; rasterizer_impl.cu:54-66,141-153. `present` is device uint8/bool [P]. */
+int gs4d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                      uint8_t* present, void* stream);
+
+/* Views into the opaque scratch chunks (device pointers), for bit-exact checks against the oracle. */
+typedef struct gs4d_state_view {
+    /* geometry chunk, P entries each */
+    const float* depths;
+    const uint8_t* clamped;         /* [P,3] */
+    const float* means2D;           /* [P,2] */
+    const float* cov3D;             /* [P,6] */
+    const float* conic_opacity;     /* [P,4] */
+    const float* rgb;               /* [P,3] */
+    const uint32_t* tiles_touched;
+    const uint32_t* point_offsets;  /* inclusive prefix sum */
+    /* binning chunk, R entries each */
+    const uint64_t* keys_unsorted;
+    const uint32_t* values_unsorted;
+    const uint64_t* keys_sorted;
+    const uint32_t* point_list;
+    /* image chunk */
+    const uint32_t* ranges;         /* [tiles,2] */
+    const float* final_T;           /* [H*W] */
+    const uint32_t* n_contrib;      /* [H*W] */
+} gs4d_state_view;
+
+int gs4d_state_view_get(int P, int R, int width, int height,
+                        char* geom_buffer, char* binning_buffer, char* img_buffer, gs4d_state_view* out);
+
+/* Sizes of the three chunks (what the allocator callbacks will be asked for). */
+size_t gs4d_geometry_bytes(int P);
+size_t gs4d_binning_bytes(int R);
+size_t gs4d_image_bytes(int width, int height);
+size_t gs4d_backward_scratch_bytes(int R);
+
+/*
+ * distCUDA2: mean_dist2[i] = mean of the 3 smallest squared distances from points[i] to the
+ * other points.  Replaces SimpleKNN::knn (simple_knn.h:15-19, simple_knn.cu:185-221).
+ * points: device [P,3] float32, mean_dist2: device [P].  Scratch comes from `alloc`.
+ */
+int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float* points, float* mean_dist2,
+                        void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GS4D_H_INCLUDED */

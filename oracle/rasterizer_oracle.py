@@ -126,7 +126,7 @@ def forward(bg, means3D, colors_precomp, opacities, scales, rotations, scale_mod
     return r
 
 
-def backward(fwd: dict, dL_dout_color, dL_dout_depth) -> dict:
+def backward(fwd: dict, dL_dout_color, dL_dout_depth, float_accum: bool = False) -> dict:
     """Mirrors Rasterizer::backward (rasterizer_impl.cu:343-444) on a forward() result."""
     L = lib()
     i = fwd["_inputs"]
@@ -146,7 +146,7 @@ def backward(fwd: dict, dL_dout_color, dL_dout_depth) -> dict:
         P, W, H, _p(fwd["ranges"]), _p(fwd["point_list"]), _f(i["bg"]), _p(fwd["means2D"]),
         _p(fwd["conic_opacity"]), _f(feat), _p(fwd["depths"]), _p(fwd["final_T"]), _p(fwd["n_contrib"]),
         _f(dL_dout_color), _f(dL_dout_depth), _p(g["dL_dmeans2D"]), _p(g["dL_dconic"]), _p(g["dL_dopacity"]),
-        _p(g["dL_dcolors"]), _p(g["dL_ddepths"]))
+        _p(g["dL_dcolors"]), _p(g["dL_ddepths"]), int(bool(float_accum)))
     cov3D = i["cov3D_precomp"] if i["cov3D_precomp"] is not None else fwd["cov3D"]
     L.gs4d_ref_preprocess_backward(
         P, D, M, _f(i["means3D"]), _p(fwd["radii"]), _f(i["sh"]), _p(fwd["clamped"]), _f(i["scales"]),

@@ -512,17 +512,22 @@ void gs4d_ref_render_forward(
 /*
  * backward.cu:415-590.  Scatter sums go to double accumulators (P x {3,4,1,3,1}) and are
  * rounded to float once at the end; everything per (pixel, Gaussian) pair is float32
- * exactly as the reference computes it.  dL_dmean2D is (P,3) with .z untouched (0),
+ * exactly as the reference computes it.  With float_accum != 0 every scatter add is rounded to
+ * float32 instead (a fixed-order stand-in for the reference's float atomics), which tests use to
+ * measure the float32 summation-order noise floor of the reference algorithm itself.
+ * dL_dmean2D is (P,3) with .z untouched (0),
  * dL_dconic is (P,4) with slot 2 untouched (0).
  */
 void gs4d_ref_render_backward(
 	int P, int W, int H, const uint32_t* ranges, const uint32_t* point_list, const float* bg,
 	const float* means2D, const float* conic_opacity, const float* colors, const float* depths,
 	const float* final_Ts, const uint32_t* n_contrib, const float* dL_dpixels, const float* dL_dpixel_depths,
-	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths)
+	float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolors, float* dL_ddepths,
+	int float_accum)
 {
 	const int gx = (W + BLOCK_X - 1) / BLOCK_X;
 	double* acc = (double*)calloc((size_t)P * 10, sizeof(double));
+#define ACC(i_, x_) do { double n_ = a[i_] + (double)(x_); a[i_] = float_accum ? (double)(float)n_ : n_; } while (0)
 	const float ddelx_dx = (float)(0.5 * W);
 	const float ddely_dy = (float)(0.5 * H);
 	for (int py = 0; py < H; py++)
@@ -566,13 +571,13 @@ void gs4d_ref_render_backward(
 					last_color[ch] = c;
 					const float dL_dchannel = dL_dpixel[ch];
 					dL_dalpha += (c - accum_rec[ch]) * dL_dchannel;
-					a[ch] += (double)(dchannel_dcolor * dL_dchannel);
+					ACC(ch, dchannel_dcolor * dL_dchannel);
 				}
 				const float c_d = depths[id];
 				accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
 				last_depth = c_d;
 				dL_dalpha += (c_d - accum_depth_rec) * dL_dpixel_depth;
-				a[3] += (double)(dpixel_depth_ddepth * dL_dpixel_depth);
+				ACC(3, dpixel_depth_ddepth * dL_dpixel_depth);
 				dL_dalpha *= T;
 				last_alpha = alpha;
 				float bg_dot_dpixel = 0;
@@ -583,12 +588,12 @@ void gs4d_ref_render_backward(
 				const float gdy = G * dy;
 				const float dG_ddelx = -gdx * co[0] - gdy * co[1];
 				const float dG_ddely = -gdy * co[2] - gdx * co[1];
-				a[4] += (double)(dL_dG * dG_ddelx * ddelx_dx);
-				a[5] += (double)(dL_dG * dG_ddely * ddely_dy);
-				a[6] += (double)(-0.5f * gdx * dx * dL_dG);
-				a[7] += (double)(-0.5f * gdx * dy * dL_dG);
-				a[8] += (double)(-0.5f * gdy * dy * dL_dG);
-				a[9] += (double)(G * dL_dalpha);
+				ACC(4, dL_dG * dG_ddelx * ddelx_dx);
+				ACC(5, dL_dG * dG_ddely * ddely_dy);
+				ACC(6, -0.5f * gdx * dx * dL_dG);
+				ACC(7, -0.5f * gdx * dy * dL_dG);
+				ACC(8, -0.5f * gdy * dy * dL_dG);
+				ACC(9, G * dL_dalpha);
 			}
 		}
 	for (int id = 0; id < P; id++) {
@@ -607,6 +612,7 @@ void gs4d_ref_render_backward(
 		dL_dopacity[id] = (float)a[9];
 	}
 	free(acc);
+#undef ACC
 }
 
 /* backward.cu:20-139 */

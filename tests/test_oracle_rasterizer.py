@@ -205,3 +205,24 @@ def test_precomputed_color_and_cov_paths_match_float64_autograd():
         got = torch.from_numpy(g[name]).double()
         assert (got - want).abs().max() / want.abs().max() < 1e-4, name
     assert (g["dL_dsh"].size == 0) and (g["dL_dscales"] == 0).all() and (g["dL_drotations"] == 0).all()
+
+
+def test_float32_summation_noise_floor_of_the_reference_algorithm():
+    """The reference sums per-pixel gradient terms with float32 atomics (backward.cu:550-587); the oracle
+    sums them in double.  Re-running the oracle with every add rounded to float32 (fixed order) shows how far
+    ANY float32 evaluation of the reference algorithm can sit from the double-accumulated result: directly
+    accumulated tensors stay ~1e-6, but dL_dscales / dL_drotations (derived from dL_dcov3D through a
+    cancelling chain, backward.cu:300-336) move by ~1e-4 of their max.  This is why the GPU parity tests use
+    1e-4 for accumulated tensors and 3e-4 for these two."""
+    a, cam = small_scene(P=1000, W=70, H=50, seed=1, s0=0.05)
+    r = run_oracle(a, cam, deg=2)
+    rng = np.random.default_rng(1)
+    gc = rng.standard_normal((3, 50, 70)).astype(np.float32)
+    gd = (rng.standard_normal((1, 50, 70)) * 0.1).astype(np.float32)
+    d = O.backward(r, gc, gd)
+    f = O.backward(r, gc, gd, float_accum=True)
+    rel = {k: np.abs(f[k].astype(np.float64) - d[k]).max() / max(np.abs(d[k]).max(), 1e-20) for k in d if d[k].size}
+    for k in ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_ddepths", "dL_dsh", "dL_dmeans3D", "dL_dcov3D"):
+        assert rel[k] < 2e-5, (k, rel[k])
+    assert 2e-5 < rel["dL_drotations"] < 3e-4, rel["dL_drotations"]
+    assert rel["dL_dscales"] < 3e-4
