@@ -1,0 +1,299 @@
+"""deform_network / Deformation, mirroring scene/deformation.py:18-298 of the reference.
+
+Same class names, constructor (`deform_network(args)` reading the same args fields), parameter
+names and shapes (a reference `deformation.pth` loads with load_state_dict), weight
+initialisation (xavier on every Linear weight, biases left at nn.Linear's default except the
+four "zero-init" heads whose biases stay 0, scene/deformation.py:92-112,253,285-289) and the
+same `forward_dynamic(points, scales, rotations, opacity, shs, time, force, prev_frames)` ->
+`(means3D, scales, rotations, opacity, shs)` contract.
+
+The computation is ONE autograd node backed by gs4d_deform_forward / gs4d_deform_backward in
+libgs4d.so (include/gs4d.h).  There is no PyTorch fallback: tensors must live on a HIP device.
+Supported = what runs in the reference: blend_time_force=True, no_do=True, prev_frames=None,
+net_width=64, grid_pe=0 (SURVEY.md "five facts" #3; scene/deformation.py:101 vs :190).
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+import torch.nn.init as init
+
+from .. import _cabi
+from .hexplane import HexPlaneField
+
+MAX_LEVELS, MAX_TRUNK = 4, 8
+FP = C.c_void_p
+
+
+class DeformDesc(C.Structure):
+    _fields_ = [("C", C.c_int), ("L", C.c_int), ("trunk_layers", C.c_int), ("pos_pe", C.c_int), ("sr_pe", C.c_int),
+                ("time_pe", C.c_int), ("force_pe", C.c_int), ("no_dx", C.c_int), ("no_ds", C.c_int), ("no_dr", C.c_int),
+                ("no_dshs", C.c_int), ("apply_rotation", C.c_int), ("use_time", C.c_int), ("use_force", C.c_int),
+                ("planes", FP * (MAX_LEVELS * 6)), ("plane_w", C.c_int * (MAX_LEVELS * 6)),
+                ("plane_h", C.c_int * (MAX_LEVELS * 6)), ("aabb", FP), ("ft_w", FP), ("ft_b", FP),
+                ("trunk_w", FP * MAX_TRUNK), ("trunk_b", FP * MAX_TRUNK), ("head_w1", FP * 4), ("head_b1", FP * 4),
+                ("head_w2", FP * 4), ("head_b2", FP * 4)]
+
+
+class DeformGrads(C.Structure):
+    _fields_ = [("planes", FP * (MAX_LEVELS * 6)), ("ft_w", FP), ("ft_b", FP), ("trunk_w", FP * MAX_TRUNK),
+                ("trunk_b", FP * MAX_TRUNK), ("head_w1", FP * 4), ("head_b1", FP * 4), ("head_w2", FP * 4),
+                ("head_b2", FP * 4)]
+
+
+def _lib():
+    L = _cabi.lib()
+    L.gs4d_deform_workspace_bytes.restype = C.c_size_t
+    L.gs4d_deform_backward_scratch_bytes.restype = C.c_size_t
+    return L
+
+
+def init_zero_(model):
+    for m in model:
+        if isinstance(m, nn.Linear):
+            init.zeros_(m.weight)
+            if m.bias is not None:
+                init.zeros_(m.bias)
+
+
+class _DeformFunction(torch.autograd.Function):
+    """points, scales, rotations, shs, time, force, cfg, n_planes, *params -> 4 outputs.
+    params = planes..., aabb, ft_w, ft_b, trunk (w,b)..., heads (w1,b1,w2,b2) x 4."""
+
+    @staticmethod
+    def _desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads):
+        d = DeformDesc()
+        d.C, d.L, d.trunk_layers = cfg["C"], cfg["L"], len(trunk) // 2
+        d.pos_pe, d.sr_pe, d.time_pe, d.force_pe = cfg["pos_pe"], cfg["sr_pe"], cfg["time_pe"], cfg["force_pe"]
+        d.no_dx, d.no_ds, d.no_dr, d.no_dshs = cfg["no_dx"], cfg["no_ds"], cfg["no_dr"], cfg["no_dshs"]
+        d.apply_rotation, d.use_time, d.use_force = cfg["apply_rotation"], cfg["use_time"], cfg["use_force"]
+        for i, p in enumerate(planes):
+            d.planes[i] = p.data_ptr()
+            d.plane_w[i], d.plane_h[i] = p.shape[3], p.shape[2]
+        d.aabb, d.ft_w, d.ft_b = aabb.data_ptr(), ft_w.data_ptr(), ft_b.data_ptr()
+        for i in range(len(trunk) // 2):
+            d.trunk_w[i], d.trunk_b[i] = trunk[2 * i].data_ptr(), trunk[2 * i + 1].data_ptr()
+        for h in range(4):
+            d.head_w1[h], d.head_b1[h] = heads[4 * h].data_ptr(), heads[4 * h + 1].data_ptr()
+            d.head_w2[h], d.head_b2[h] = heads[4 * h + 2].data_ptr(), heads[4 * h + 3].data_ptr()
+        return d
+
+    @staticmethod
+    def _split(cfg, params):
+        n_planes = cfg["L"] * 6
+        planes = [p.contiguous(memory_format=torch.channels_last) for p in params[:n_planes]]
+        aabb, ft_w, ft_b = (t.contiguous() for t in params[n_planes:n_planes + 3])
+        n_trunk = cfg["trunk_layers"]
+        trunk = [t.contiguous() for t in params[n_planes + 3:n_planes + 3 + 2 * n_trunk]]
+        heads = [t.contiguous() for t in params[n_planes + 3 + 2 * n_trunk:]]
+        assert len(heads) == 16
+        return planes, aabb, ft_w, ft_b, trunk, heads
+
+    @staticmethod
+    def forward(ctx, points, scales, rotations, shs, time, force, cfg, *params):
+        L = _lib()
+        dev = points.device
+        if dev.type != "cuda":
+            raise RuntimeError("the deformation field runs on a HIP device only; there is no CPU path")
+        P = points.shape[0]
+        f32 = lambda t: t.detach().to(torch.float32).contiguous()
+        points_, scales_, rot_, shs_ = f32(points), f32(scales), f32(rotations), f32(shs)
+        time_, force_ = f32(time).reshape(-1), f32(force).reshape(-1)
+        if rot_.data_ptr() % 16:
+            rot_ = rot_.clone()
+        planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
+        d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
+        o_xyz, o_sc, o_rot, o_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, shs_))
+        ws = torch.empty(max(int(L.gs4d_deform_workspace_bytes(C.byref(d), C.c_int(P))), 256), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.gs4d_deform_forward(C.byref(d), C.c_int(P), _cabi.ptr(points_), _cabi.ptr(scales_), _cabi.ptr(rot_),
+                                       _cabi.ptr(shs_), _cabi.ptr(time_), _cabi.ptr(force_), _cabi.ptr(o_xyz),
+                                       _cabi.ptr(o_sc), _cabi.ptr(o_rot), _cabi.ptr(o_shs), _cabi.ptr(ws),
+                                       _cabi.current_stream(dev))
+        _cabi.check(rc, "gs4d_deform_forward")
+        ctx.cfg = cfg
+        ctx.save_for_backward(points_, scales_, rot_, time_, force_, ws, *params)
+        return o_xyz, o_sc, o_rot, o_shs
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_sc, g_rot, g_shs):
+        L = _lib()
+        cfg = ctx.cfg
+        points_, scales_, rot_, time_, force_, ws, *params = ctx.saved_tensors
+        dev = points_.device
+        P = points_.shape[0]
+        planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
+        d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
+        zeros = lambda t, cl=False: torch.zeros_like(t, memory_format=torch.channels_last if cl else torch.contiguous_format)
+        gp = [zeros(p, True) for p in planes]
+        g_ftw, g_ftb = zeros(ft_w), zeros(ft_b)
+        gt = [zeros(t) for t in trunk]
+        gh = [zeros(t) for t in heads]
+        g = DeformGrads()
+        for i, t in enumerate(gp):
+            g.planes[i] = t.data_ptr()
+        g.ft_w, g.ft_b = g_ftw.data_ptr(), g_ftb.data_ptr()
+        for i in range(len(trunk) // 2):
+            g.trunk_w[i], g.trunk_b[i] = gt[2 * i].data_ptr(), gt[2 * i + 1].data_ptr()
+        for h in range(4):
+            g.head_w1[h], g.head_b1[h] = gh[4 * h].data_ptr(), gh[4 * h + 1].data_ptr()
+            g.head_w2[h], g.head_b2[h] = gh[4 * h + 2].data_ptr(), gh[4 * h + 3].data_ptr()
+        gz = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
+        g_xyz, g_sc, g_rot = gz(g_xyz, points_), gz(g_sc, scales_), gz(g_rot, rot_)
+        g_shs = gz(g_shs, torch.empty(P, 16, 3, device=dev))
+        if g_rot.data_ptr() % 16:
+            g_rot = g_rot.clone()
+        d_xyz, d_sc, d_rot, d_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, g_shs))
+        scratch = torch.empty(max(int(L.gs4d_deform_backward_scratch_bytes(C.byref(d), C.c_int(P))), 256),
+                              dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.gs4d_deform_backward(C.byref(d), C.byref(g), C.c_int(P), _cabi.ptr(points_), _cabi.ptr(scales_),
+                                        _cabi.ptr(rot_), _cabi.ptr(time_), _cabi.ptr(force_), _cabi.ptr(g_xyz),
+                                        _cabi.ptr(g_sc), _cabi.ptr(g_rot), _cabi.ptr(g_shs), _cabi.ptr(d_xyz),
+                                        _cabi.ptr(d_sc), _cabi.ptr(d_rot), _cabi.ptr(d_shs), _cabi.ptr(ws),
+                                        _cabi.ptr(scratch), _cabi.current_stream(dev))
+        _cabi.check(rc, "gs4d_deform_backward")
+        param_grads = gp + [None, g_ftw, g_ftb] + gt + gh
+        return (d_xyz, d_sc, d_rot, d_shs, None, None, None, *param_grads)
+
+
+class Deformation(nn.Module):
+    def __init__(self, D=8, W=256, grid_pe=0, args=None):
+        super().__init__()
+        self.D, self.W, self.args = D, W, args
+        self.grid = HexPlaneField(args.bounds, args.kplanes_config, args.multires, W)
+        self.blend_time_force = args.blend_time_force
+        self.ratio = 0
+        self.posbase_pe, self.scale_rotation_pe, self.opacity_pe = args.posebase_pe, args.scale_rotation_pe, args.opacity_pe
+        self.grid_pe, self.force_pe, self.time_pe = args.grid_pe, args.force_pe, args.time_pe
+        self.extra_point_dim = args.posebase_pe * 2 * 3
+        self.extra_scale_dim = args.scale_rotation_pe * 2 * 3
+        self.extra_rotation_dim = args.scale_rotation_pe * 2 * 4
+        self.extra_opacity_dim = args.opacity_pe * 2 * 3
+        self.prev_frames = args.prev_frames
+        self.prev_frames_out_dim = 16
+        self.create_net()
+
+    @property
+    def get_aabb(self):
+        return self.grid.get_aabb
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.grid.set_aabb(xyz_max, xyz_min)
+
+    def create_net(self):
+        W = self.W
+        self.prev_frame_encoder = nn.Sequential(  # unused unless prev_frames is given; kept for state_dict parity
+            nn.Conv2d(3, 16, kernel_size=5, stride=3), nn.ReLU(), nn.Conv2d(16, 64, kernel_size=5, stride=3), nn.ReLU(),
+            nn.Conv2d(64, 128, kernel_size=5, stride=4), nn.ReLU(), nn.Conv2d(128, 128, kernel_size=3, stride=2), nn.ReLU(),
+            nn.Flatten(), nn.Linear(128 * 5 * 5, 128), nn.ReLU(), nn.Linear(128, self.prev_frames_out_dim))
+        total_prev_frames_dim = self.prev_frames * self.prev_frames_out_dim
+        grid_out_dim = self.grid.feat_dim + self.grid_pe * self.grid.feat_dim * 2
+        extra = 1 + 2 * self.force_pe + 1 + 2 * self.time_pe
+        self.feature_out1 = nn.Linear(grid_out_dim + total_prev_frames_dim, grid_out_dim)
+        layers = [nn.Linear(grid_out_dim, W)]
+        for _ in range(self.D - 1):
+            layers += [nn.ReLU(), nn.Linear(W, W)]
+        self.feature_out2 = nn.Sequential(*layers)
+        head = lambda in_extra, out: nn.Sequential(nn.ReLU(), nn.Linear(W + in_extra + extra, W), nn.ReLU(), nn.Linear(W, out))
+        self.pos_deform = head(self.extra_point_dim, 3)
+        self.scales_deform = head(self.extra_scale_dim, 3)
+        init_zero_(self.scales_deform)
+        self.rotations_deform = head(self.extra_rotation_dim, 4)
+        init_zero_(self.rotations_deform)
+        self.opacity_deform = head(self.extra_opacity_dim, 1)
+        init_zero_(self.opacity_deform)
+        self.shs_deform = head(0, 16 * 3)
+        init_zero_(self.shs_deform)
+        self.force_embedder = nn.Linear(2, 1)
+        if self.blend_time_force:
+            self.force_time_embed = nn.Linear(2, 1)
+
+    @property
+    def get_empty_ratio(self):
+        return self.ratio
+
+    def _config(self):
+        a = self.args
+        if not self.blend_time_force:
+            raise NotImplementedError("only blend_time_force=True is supported (the reference's other path raises "
+                                      "IndexError at scene/hexplane.py:116)")
+        if not a.no_do:
+            raise NotImplementedError("no_do=False feeds opacity_deform the wrong input width in the reference "
+                                      "(scene/deformation.py:101 vs :190) and cannot run there either")
+        if self.W != 64 or self.grid_pe != 0:
+            raise NotImplementedError("net_width must be 64 and grid_pe 0")
+        kc = a.kplanes_config
+        return dict(C=int(kc["output_coordinate_dim"]), L=len(a.multires), trunk_layers=max(self.D, 1),
+                    pos_pe=int(self.posbase_pe), sr_pe=int(self.scale_rotation_pe), time_pe=int(self.time_pe),
+                    force_pe=int(self.force_pe), no_dx=int(bool(a.no_dx)), no_ds=int(bool(a.no_ds)),
+                    no_dr=int(bool(a.no_dr)), no_dshs=int(bool(a.no_dshs)), apply_rotation=int(bool(a.apply_rotation)),
+                    use_time=int(bool(a.use_time)), use_force=int(bool(a.use_force)))
+
+    def _params(self):
+        planes = [p for level in self.grid.grids for p in level]
+        trunk = []
+        for m in self.feature_out2:
+            if isinstance(m, nn.Linear):
+                trunk += [m.weight, m.bias]
+        heads = []
+        for h in (self.pos_deform, self.scales_deform, self.rotations_deform, self.shs_deform):
+            heads += [h[1].weight, h[1].bias, h[3].weight, h[3].bias]
+        return planes + [self.grid.aabb, self.force_time_embed.weight, self.force_time_embed.bias] + trunk + heads
+
+    def forward_dynamic(self, points, scales, rotations, opacity, shs, time, force, prev_frames=None):
+        if prev_frames is not None:
+            raise NotImplementedError("prev_frames conditioning is outside the hot path (SURVEY.md section 8)")
+        out = _DeformFunction.apply(points, scales, rotations, shs, time, force, self._config(), *self._params())
+        return out[0], out[1], out[2], opacity[:, :1], out[3]
+
+    def get_mlp_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" not in n]
+
+    def get_grid_parameters(self):
+        return [p for n, p in self.named_parameters() if "grid" in n]
+
+    def enable_extra_deform(self):
+        self.args.no_ds = self.args.no_dr = self.args.no_dshs = False
+
+    def disable_extra_deform(self):
+        self.args.no_ds = self.args.no_dr = self.args.no_dshs = True
+
+
+def initialize_weights(m):
+    if isinstance(m, nn.Linear):
+        init.xavier_uniform_(m.weight, gain=1)  # the reference re-inits the weight (twice) and never the bias
+
+
+class deform_network(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.deformation_net = Deformation(W=args.net_width, D=args.defor_depth, grid_pe=args.grid_pe, args=args)
+        for name, n in (("pos_poc", args.posebase_pe), ("rotation_scaling_poc", args.scale_rotation_pe),
+                        ("opacity_poc", args.opacity_pe), ("force_poc", args.force_pe), ("time_poc", args.time_pe)):
+            self.register_buffer(name, torch.FloatTensor([(2 ** i) for i in range(n)]))
+        self.apply(initialize_weights)
+        self.recur = False
+        self.prev_frames = 0
+
+    @property
+    def get_aabb(self):
+        return self.deformation_net.get_aabb
+
+    @property
+    def get_empty_ratio(self):
+        return self.deformation_net.get_empty_ratio
+
+    def forward_dynamic(self, points_in, scales_in, rotations_in, opacity_in, shs_in, times_sel_in, force_in, prev_frames=None):
+        # the positional encodings (poc_fre, scene/deformation.py:291-298) are evaluated inside the HIP path
+        return self.deformation_net.forward_dynamic(points_in, scales_in, rotations_in, opacity_in, shs_in,
+                                                    times_sel_in, force_in, prev_frames)
+
+    def forward(self, *args):
+        return self.forward_dynamic(*args)
+
+    def get_mlp_parameters(self):
+        return self.deformation_net.get_mlp_parameters()
+
+    def get_grid_parameters(self):
+        return self.deformation_net.get_grid_parameters()

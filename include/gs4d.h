@@ -13,8 +13,8 @@
  *   gs4d_mark_visible         <->  CudaRasterizer::Rasterizer::markVisible RAST/cuda_rasterizer/rasterizer.h:24-29
  *   gs4d_knn_mean_dist2       <->  SimpleKNN::knn                          submodules/simple-knn/simple_knn.h:15-19
  *   gs4d_alloc_fn             <->  std::function<char*(size_t)> resize lambdas, RAST/rasterize_points.cu:27-33
- *   gs4d_hexplane_*           <->  HexPlaneField.get_density / interpolate_ms_features, scene/hexplane.py:100-131,192-215
- *   gs4d_deform_mlp_*         <->  Deformation.query_time_force trunk + heads, scene/deformation.py:128-200
+ *   gs4d_deform_forward/backward <-> deform_network.forward_dynamic (PyTorch in the reference):
+ *                                  scene/hexplane.py:100-131,192-215 + scene/deformation.py:128-200,265-298
  *
  * The scratch buffers (geometry / binning / image) are opaque byte chunks owned by the
  * caller exactly as in the reference (they are only round-tripped from forward to
@@ -150,6 +150,80 @@ size_t gs4d_backward_scratch_bytes(int R);
  */
 int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float* points, float* mean_dist2,
                         void* stream);
+
+/*
+ * HexPlane deformation field.  The reference implements it in PyTorch
+ * (scene/hexplane.py:100-131,192-215 gathers; scene/deformation.py:128-200,265-298 trunk, heads,
+ * positional encodings; utils/graphics_utils.py:110-133 quaternion update), so there is no native
+ * interface to mirror: these two entry points bind the whole of
+ * deform_network.forward_dynamic(points, scales, rotations, opacity, shs, time, force, None)
+ * and its backward.  Only the path that runs in the reference is supported:
+ * blend_time_force = True, no_do = True (opacity passes through), prev_frames = None, net_width = 64.
+ *
+ * All pointers are device pointers.  Weights use the reference's nn.Linear layout [out][in]
+ * row-major.  Plane l*6+i is the reference's grids[l][i] (pairs xy,xz,xt,yz,yt,zt) stored
+ * CHANNELS-LAST: [height][width][C] (torch.channels_last of the reference's [1,C,H,W] shape),
+ * width = resolution of the pair's first axis, height = of its second.
+ */
+#define GS4D_MAX_LEVELS 4
+#define GS4D_MAX_TRUNK 8
+typedef struct gs4d_deform_desc {
+    int C;                    /* channels per plane (4..256, power of two) */
+    int L;                    /* multi-resolution levels */
+    int trunk_layers;         /* max(defor_depth, 1): Linear(L*C,64) then (ReLU, Linear(64,64)) ... */
+    int pos_pe, sr_pe, time_pe, force_pe;   /* numbers of PE frequencies */
+    int no_dx, no_ds, no_dr, no_dshs, apply_rotation, use_time, use_force;
+    const float* planes[GS4D_MAX_LEVELS * 6];
+    int plane_w[GS4D_MAX_LEVELS * 6];
+    int plane_h[GS4D_MAX_LEVELS * 6];
+    const float* aabb;        /* [2][3]: row 0 = xyz_max, row 1 = xyz_min (scene/hexplane.py:188-190) */
+    const float* ft_w;        /* force_time_embed.weight [1][2] */
+    const float* ft_b;        /* force_time_embed.bias [1] */
+    const float* trunk_w[GS4D_MAX_TRUNK];
+    const float* trunk_b[GS4D_MAX_TRUNK];
+    const float* head_w1[4];  /* pos, scales, rotations, shs: first Linear [64][in_h] */
+    const float* head_b1[4];
+    const float* head_w2[4];  /* second Linear [out_h][64], out = 3,3,4,48 */
+    const float* head_b2[4];
+} gs4d_deform_desc;
+
+/* Gradient destinations, same shapes as the parameters above; every one must be zero-initialised
+ * by the caller (plane gradients are accumulated with float atomics). */
+typedef struct gs4d_deform_grads {
+    float* planes[GS4D_MAX_LEVELS * 6];
+    float* ft_w;
+    float* ft_b;
+    float* trunk_w[GS4D_MAX_TRUNK];
+    float* trunk_b[GS4D_MAX_TRUNK];
+    float* head_w1[4];
+    float* head_b1[4];
+    float* head_w2[4];
+    float* head_b2[4];
+} gs4d_deform_grads;
+
+/* Bytes of the activation workspace the forward fills and the backward re-reads, and of the
+ * backward's own scratch. */
+size_t gs4d_deform_workspace_bytes(const gs4d_deform_desc* d, int P);
+size_t gs4d_deform_backward_scratch_bytes(const gs4d_deform_desc* d, int P);
+
+/* points [P,3], scales [P,3], rotations [P,4], shs [P,16,3], time [P], force [P] ->
+ * out_means3D [P,3], out_scales [P,3], out_rotations [P,4], out_shs [P,16,3].
+ * workspace: gs4d_deform_workspace_bytes(), 256-byte aligned, kept by the caller for the backward. */
+int gs4d_deform_forward(const gs4d_deform_desc* d, int P,
+                        const float* points, const float* scales, const float* rotations, const float* shs,
+                        const float* time, const float* force,
+                        float* out_means3D, float* out_scales, float* out_rotations, float* out_shs,
+                        char* workspace, void* stream);
+
+/* dL_d(out_*) -> dL_d(points, scales, rotations, shs) (written, not accumulated) and parameter
+ * gradients accumulated into `g`.  scratch: gs4d_deform_backward_scratch_bytes(). */
+int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P,
+                         const float* points, const float* scales, const float* rotations,
+                         const float* time, const float* force,
+                         const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations,
+                         const float* dL_dshs,
+                         float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in, float* dL_dshs_in,
+                         char* workspace, char* scratch, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,119 @@
+"""GPU parity of the HIP deformation field (through the reference-shaped deform_network module and the
+C ABI) against (a) golden vectors produced by the reference's own Python and (b) the CPU oracle at a
+larger size.  Tolerances: forward 1e-5 (abs, relative to max(1, |x|max)), gradients 1e-4 relative to the
+tensor's max (plane gradients are summed with float atomics)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import pkg
+from golden_utils import CASES, load_case
+
+pytestmark = pytest.mark.gpu
+ORDER = ("means3D", "scales", "rotations", "opacity", "shs")
+
+
+def make_args(cfg):
+    a = types.SimpleNamespace()
+    a.net_width, a.defor_depth, a.posebase_pe = cfg.net_width, cfg.defor_depth, cfg.posebase_pe
+    a.scale_rotation_pe, a.opacity_pe, a.grid_pe = cfg.scale_rotation_pe, cfg.opacity_pe, 0
+    a.force_pe, a.time_pe, a.bounds = cfg.force_pe, cfg.time_pe, cfg.bounds
+    a.kplanes_config = {"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": cfg.plane_channels,
+                        "resolution": list(cfg.resolution)}
+    a.multires = list(cfg.multires)
+    a.no_dx, a.no_ds, a.no_dr, a.no_do, a.no_dshs = cfg.no_dx, cfg.no_ds, cfg.no_dr, cfg.no_do, cfg.no_dshs
+    a.empty_voxel, a.static_mlp, a.apply_rotation = False, False, cfg.apply_rotation
+    a.use_time, a.use_force, a.blend_time_force, a.prev_frames, a.no_grid = cfg.use_time, cfg.use_force, True, 0, False
+    return a
+
+
+def build_net(cfg, sd):
+    D = pkg("scene.deformation")
+    net = D.deform_network(make_args(cfg))
+    missing, unexpected = net.load_state_dict(sd, strict=False)
+    assert not unexpected, unexpected                      # every live reference key exists here
+    assert all(any(s in m for s in ("prev_frame_encoder", "feature_out1", "force_embedder", "feature_aggr", "opacity_deform"))
+               for m in missing), missing                  # only the dead parameters were left out of the fixture
+    return net.cuda()
+
+
+def close(name, got, want, tol):
+    got, want = got.detach().cpu().double(), want.double()
+    err = float((got - want).abs().max()) / max(1.0, float(want.abs().max())) if tol == "fwd" else \
+        float((got - want).abs().max()) / max(float(want.abs().max()), 1e-20)
+    lim = 1e-5 if tol == "fwd" else 1e-4
+    assert err <= lim, (name, err)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_matches_reference_golden(case):
+    cfg, sd, ins, outs, ws, gins, grads = load_case(case)
+    net = build_net(cfg, sd)
+    x = {k: ins[k].cuda().requires_grad_(True) for k in ("points", "scales", "rotations", "opacity", "shs")}
+    got = net.forward_dynamic(x["points"], x["scales"], x["rotations"], x["opacity"], x["shs"], ins["time"].cuda(),
+                              ins["force"].cuda(), None)
+    for n, g in zip(ORDER, got):
+        close(n, g, outs[n], "fwd")
+    sum((g * ws[n].cuda()).sum() for n, g in zip(ORDER, got)).backward()
+    for k, want in gins.items():
+        if want.numel():
+            close("d" + k, x[k].grad, want, "bwd")
+    params = dict(net.named_parameters())
+    for k, want in grads.items():
+        g = params[k].grad
+        assert g is not None, k
+        close(k, g, want, "bwd")
+
+
+def test_matches_oracle_at_scale_mutant_shape():
+    """C2's network shape (arguments/dnerf/others/mutant.py + dnerf_default.py) on 20k points vs the CPU oracle."""
+    from oracle import deformation_ref as R
+    cfg = R.DeformConfig(defor_depth=0, plane_channels=32, resolution=[64, 64, 64, 75], multires=[1, 2])
+    torch.manual_seed(3)
+    net = pkg("scene.deformation").deform_network(make_args(cfg))
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "deform" in n and "bias" in n:
+                p.add_(0.02 * torch.randn_like(p))
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    P = 20000
+    g = torch.Generator().manual_seed(5)
+    ins = dict(points=torch.rand(P, 3, generator=g) * 3.4 - 1.7, scales=torch.randn(P, 3, generator=g) * 0.5 - 3,
+               rotations=torch.randn(P, 4, generator=g), opacity=torch.randn(P, 1, generator=g),
+               shs=torch.randn(P, 16, 3, generator=g) * 0.3)
+    time, force = torch.full((P, 1), 0.61), torch.zeros(P, 1)
+    ws = [torch.randn(s, generator=g) for s in ((P, 3), (P, 3), (P, 4), (P, 1), (P, 16, 3))]
+    # oracle
+    sdo = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "poc" not in k and "aabb" not in k) for k, v in sd.items()}
+    xo = {k: v.clone().requires_grad_(True) for k, v in ins.items()}
+    want = R.forward_dynamic(sdo, cfg, xo["points"], xo["scales"], xo["rotations"], xo["opacity"], xo["shs"], time, force)
+    sum((o * w).sum() for o, w in zip(want, ws)).backward()
+    # HIP
+    net = net.cuda()
+    xg = {k: v.cuda().requires_grad_(True) for k, v in ins.items()}
+    got = net.forward_dynamic(xg["points"], xg["scales"], xg["rotations"], xg["opacity"], xg["shs"], time.cuda(), force.cuda(), None)
+    for n, a, b in zip(ORDER, got, want):
+        close(n, a, b.detach(), "fwd")
+    sum((o * w.cuda()).sum() for o, w in zip(got, ws)).backward()
+    for k in ("points", "scales", "rotations", "shs"):
+        close("d" + k, xg[k].grad, xo[k].grad, "bwd")
+    for k, p in net.named_parameters():
+        if sdo[k].grad is not None:
+            assert p.grad is not None, k
+            close(k, p.grad, sdo[k].grad, "bwd")
+
+
+def test_unsupported_configurations_fail_loudly():
+    from oracle import deformation_ref as R
+    cfg = R.DeformConfig(plane_channels=8, resolution=[4, 4, 4, 3], multires=[1])
+    a = make_args(cfg)
+    a.no_do = False
+    net = pkg("scene.deformation").deform_network(a).cuda()
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    with pytest.raises(NotImplementedError):
+        net.forward_dynamic(z(4, 3), z(4, 3), z(4, 4), z(4, 1), z(4, 16, 3), z(4, 1), z(4, 1), None)
+    a.no_do = True
+    with pytest.raises(RuntimeError, match="HIP device"):
+        net.cpu().forward_dynamic(*(t.cpu() for t in (z(4, 3), z(4, 3), z(4, 4), z(4, 1), z(4, 16, 3), z(4, 1), z(4, 1))), None)
