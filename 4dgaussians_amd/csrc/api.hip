@@ -22,6 +22,54 @@ void gs4d_set_error(const char* fmt, ...)
     va_end(ap);
 }
 
+// ---------------------------------------------------------------- per-stage timing
+#include <mutex>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec { std::string stage; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_open;                       // recorded, not yet resolved
+struct ProfSum { std::string stage; double ms; long calls; };
+std::vector<ProfSum> g_prof_sums;
+void prof_resolve_locked()
+{
+    for (auto& r : g_prof_open) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            bool found = false;
+            for (auto& s : g_prof_sums)
+                if (s.stage == r.stage) { s.ms += ms; s.calls++; found = true; break; }
+            if (!found) g_prof_sums.push_back({r.stage, ms, 1});
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    g_prof_open.clear();
+}
+}  // namespace
+
+Gs4dProfScope::Gs4dProfScope(const char* stage, hipStream_t s) : slot(-1), stream(s)
+{
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r;
+    r.stage = stage;
+    if (hipEventCreate(&r.a) != hipSuccess) return;
+    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+    (void)hipEventRecord(r.a, s);
+    g_prof_open.push_back(r);
+    slot = (int)g_prof_open.size() - 1;
+}
+
+Gs4dProfScope::~Gs4dProfScope()
+{
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (slot < (int)g_prof_open.size()) (void)hipEventRecord(g_prof_open[slot].b, stream);
+}
+
 // ---------------------------------------------------------------- chunk layouts
 GeomState GeomState::from_chunk(char*& chunk, size_t P)
 {
@@ -96,7 +144,35 @@ static int sort_passes(int W, int H)
 extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
-int gs4d_abi_version(void) { return 1; }
+int gs4d_abi_version(void) { return 2; }
+
+void gs4d_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+void gs4d_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_resolve_locked();
+    g_prof_sums.clear();
+}
+
+int gs4d_profile_read(const char* stage, double* total_ms, long* calls)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_resolve_locked();
+    for (auto& s : g_prof_sums)
+        if (s.stage == stage) {
+            if (total_ms) *total_ms = s.ms;
+            if (calls) *calls = s.calls;
+            return GS4D_OK;
+        }
+    if (total_ms) *total_ms = 0.0;
+    if (calls) *calls = 0;
+    return GS4D_OK;
+}
 
 size_t gs4d_geometry_bytes(int P) { return GeomState::required((size_t)P); }
 size_t gs4d_binning_bytes(int R) { return BinningState::required((size_t)R); }

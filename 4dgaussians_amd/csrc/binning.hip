@@ -342,6 +342,7 @@ int gs4d_radix_sort_pairs(uint32_t R, int passes, const uint64_t* keys_in, const
 
 int gs4d_launch_scan(int P, GeomState& g, int debug, hipStream_t s)
 {
+    GS4D_PROF("scan", s);
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.block_offsets,
                        g.counters);
@@ -354,9 +355,12 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
 {
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
+    {
+    GS4D_PROF("emit_keys", s);
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                        radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted);
     GS4D_LAUNCH_CHECK("emit_keys", debug, s);
+    }
 
     GS4D_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
     if (R <= 0) return GS4D_OK;
@@ -364,10 +368,15 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     const uint32_t bits = 32 + gs4d_higher_msb((uint32_t)(gx * gy));
     const int passes = (int)((bits + 7) / 8);
     int where = 0;
-    int rc = gs4d_radix_sort_pairs((uint32_t)R, passes, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
+    int rc;
+    {
+    GS4D_PROF("radix_sort", s);
+    rc = gs4d_radix_sort_pairs((uint32_t)R, passes, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
                                    b.hist, &where, debug, s);
+    }
     if (rc) return rc;
     b.sorted = where;
+    GS4D_PROF("tile_ranges", s);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
                        b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, im.ranges, b.inv);
     GS4D_LAUNCH_CHECK("tile_ranges", debug, s);

@@ -211,6 +211,7 @@ int gs4d_launch_blend_backward(int W, int H, int R, const GeomState& g, const Bi
                                const float* dL_dpix_depth, float* inst_grad, int debug, hipStream_t s)
 {
     (void)R;
+    GS4D_PROF("blend_backward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
     hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3(gx, gy), dim3(GS4D_TILE_PIX), 0, s, W, H, gx, im.ranges,

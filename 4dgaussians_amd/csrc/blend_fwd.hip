@@ -138,6 +138,7 @@ int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningSta
                               const float* features, const float* bg, float* out_color, float* out_depth, int debug,
                               hipStream_t s)
 {
+    GS4D_PROF("blend_forward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
     hipLaunchKernelGGL(exact ? blend_forward_kernel<true> : blend_forward_kernel<false>, dim3(gx, gy), dim3(GS4D_TILE_PIX), 0, s, W, H, gx, im.ranges,

@@ -742,12 +742,14 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
     int lpp_shift = 0;
     while ((1 << lpp_shift) < d->C / 4) lpp_shift++;
     {
+        GS4D_PROF("hexplane_forward", s);
         const size_t threads = (size_t)P << lpp_shift;
         hipLaunchKernelGGL(hexplane_forward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, d->C,
                            d->L, lpp_shift, T, d->aabb, points, time, force, d->ft_w, d->ft_b, d->use_time,
                            d->use_force, w.tprime, w.feat, l.F);
         GS4D_LAUNCH_CHECK("hexplane_forward", 0, s);
     }
+    GS4D_PROF("mlp_forward", s);
     PeArgs pa = {P, l.ldz, l.oX, l.oS, l.oR, l.oT, l.oF, l.Kz, d->pos_pe, d->sr_pe, d->time_pe, d->force_pe,
                  d->use_time, d->use_force};
     {
@@ -826,6 +828,8 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
                   nullptr);
     const int nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
 
+    Gs4dProfScope* mlp_scope = new Gs4dProfScope("mlp_backward", s);
+    struct ScopeGuard { Gs4dProfScope*& p; ~ScopeGuard() { delete p; } } mlp_guard{mlp_scope};
     OutArgs oa = {P, d->no_dx, d->no_ds, d->no_dr, d->no_dshs, d->apply_rotation};
     hipLaunchKernelGGL(outputs_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, oa, w.O, rotations,
                        dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dO, dL_dpoints, dL_dscales_in,
@@ -941,8 +945,11 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
                            scales, rotations, dZ, dL_dpoints, dL_dscales_in, dL_drotations_in);
         GS4D_LAUNCH_CHECK("pe_backward", 0, s);
     }
+    delete mlp_scope;
+    mlp_scope = nullptr;
     // planes, xyz through the planes, t'
     {
+        GS4D_PROF("hexplane_backward", s);
         PlaneTable T = {};
         for (int i = 0; i < d->L * 6; i++) {
             if (!g->planes[i]) { gs4d_set_error("deform backward: plane gradient %d is null", i); return GS4D_EINVAL; }

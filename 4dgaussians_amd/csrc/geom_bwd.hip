@@ -353,6 +353,7 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
                               float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
                               hipStream_t s)
 {
+    GS4D_PROF("geom_backward", s);
     GeomBwdArgs A;
     A.P = P; A.D = D; A.M = M; A.W = W; A.H = H;
     A.means3D = means3D; A.radii = radii; A.shs = shs; A.clamped = g.clamped;

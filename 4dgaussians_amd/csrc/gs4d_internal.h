@@ -32,6 +32,16 @@ void gs4d_set_error(const char* fmt, ...);
         }                                                                                 \
     } while (0)
 
+// Optional per-stage device timing (HIP events on the launch stream), off by default.
+// See gs4d_profile_enable / gs4d_profile_read in include/gs4d.h.
+struct Gs4dProfScope {
+    int slot;
+    hipStream_t stream;
+    Gs4dProfScope(const char* stage, hipStream_t s);
+    ~Gs4dProfScope();
+};
+#define GS4D_PROF(stage, stream) Gs4dProfScope gs4d_prof_scope_(stage, stream)
+
 static inline size_t gs4d_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <typename T>

@@ -179,6 +179,7 @@ extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, 
         gs4d_set_error("gs4d_knn_mean_dist2: bad arguments");
         return GS4D_EINVAL;
     }
+    GS4D_PROF("knn", s);
     const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
     const int nred = min(1024, (P + 255) / 256);
     // carve scratch

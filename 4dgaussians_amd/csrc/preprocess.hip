@@ -168,6 +168,7 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
                            float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s)
 {
+    GS4D_PROF("preprocess", s);
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;

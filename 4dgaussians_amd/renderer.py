@@ -1,0 +1,75 @@
+"""Render orchestration for the hot path: the counterpart of gaussian_renderer/renderer.py's
+render() (:82-221) and render_for_image() (:258-329) restricted to what SURVEY.md section 8 puts
+in scope -- settings, one deformation query, the three activations
+(scene/gaussian_model.py:38-43: exp / L2-normalise / sigmoid) and the rasterizer call.  The
+fork-specific regularisers (two extra deformation queries + the k=100 kNN) are "next" rows.
+
+Host-side plumbing only: all compute happens in libgs4d.so through the two drop-in modules.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+
+
+class GaussianParams(nn.Module):
+    """The six per-Gaussian parameter tensors of scene/gaussian_model.py:176-183 (59 floats per Gaussian)."""
+
+    def __init__(self, raw: dict, device):
+        super().__init__()
+        t = lambda a: nn.Parameter(torch.from_numpy(np.ascontiguousarray(a)).to(device))
+        self._xyz = t(raw["xyz"])
+        self._features = t(raw["sh"])            # (P,16,3) as returned by get_features
+        self._opacity = t(raw["opacity_logit"])
+        self._scaling = t(raw["log_scales"])
+        self._rotation = t(raw["rot"])
+        self.active_sh_degree = 3
+
+
+class Camera:
+    def __init__(self, cam, device, time: float = 0.0, force: float = 0.0):
+        self.image_width, self.image_height = cam.image_width, cam.image_height
+        self.FoVx, self.FoVy = cam.FoVx, cam.FoVy
+        self.world_view_transform = torch.from_numpy(cam.viewmatrix).to(device)
+        self.full_proj_transform = torch.from_numpy(cam.projmatrix).to(device)
+        self.camera_center = torch.from_numpy(cam.campos).to(device)
+        self.time, self.force = float(time), float(force)
+
+
+def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
+           scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False):
+    """-> (image, screenspace_points, visibility_filter, radii, depth), as the first five items of the
+    reference's 7-tuple (renderer.py:221)."""
+    screenspace_points = torch.zeros_like(pc._xyz, requires_grad=torch.is_grad_enabled())
+    if screenspace_points.requires_grad:
+        screenspace_points.retain_grad()
+    settings = GaussianRasterizationSettings(
+        image_height=int(cam.image_height), image_width=int(cam.image_width),
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+        sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
+    rasterizer = GaussianRasterizer(raster_settings=settings)
+    means3D, opacity, shs, scales, rotations = pc._xyz, pc._opacity, pc._features, pc._scaling, pc._rotation
+    if "coarse" not in stage and deform is not None:
+        n = means3D.shape[0]
+        time = torch.full((n, 1), cam.time, dtype=torch.float32, device=means3D.device)
+        force = torch.full((n, 1), cam.force, dtype=torch.float32, device=means3D.device)
+        means3D, scales, rotations, opacity, shs = deform.forward_dynamic(means3D, scales, rotations, opacity, shs,
+                                                                          time, force, None)
+    scales = torch.exp(scales)
+    rotations = torch.nn.functional.normalize(rotations)
+    opacity = torch.sigmoid(opacity)
+    image, radii, depth = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
+                                     opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+    return image, screenspace_points, radii > 0, radii, depth
+
+
+@torch.no_grad()
+def render_for_image(cam: Camera, pc: GaussianParams, deform, bg_color, scaling_modifier=1.0, stage="fine"):
+    return render(cam, pc, deform, bg_color, scaling_modifier, stage)[0]

@@ -1,0 +1,268 @@
+"""bench.py -- headline benchmark of the MI355X 4DGS render path.
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): fine-stage train iterations/s, one iteration = forward + backward of ONE
+view: HexPlane deformation query -> activations -> rasterizer forward -> L1 loss -> rasterizer
+backward -> deformation backward (+ the gradient all-reduce when N > 1).  Optimizer / densify are
+outside the metric.  Workload: BASELINE.json configs[1] ("C2"): 800x800,
+100k Gaussians, SH degree 3, mutant-shaped deformation network, synthetic seeded data.
+Scaling is weak: every rank renders its own view of the same scene each step (view-parallel DP).
+
+`--mode fps` times render_for_image (deformation forward + rasterizer forward, no grad) instead.
+
+One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline      -- for the dominant kernel (blend_backward): algorithmic bytes per launch / its
+                   average duration measured with HIP events on the launch stream in the timed region
+  cpu_baseline  -- the CPU oracle (scalar C rasterizer + PyTorch-CPU deformation) on one core for the
+                   same workload, rank 0 / N == 1 only
+  stages_ms     -- average device milliseconds of every kernel stage (same HIP-event mechanism)
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
+FP32_PEAK_TFLOPS = 157.3   # vector / f32-MFMA peak
+
+STAGES = ("hexplane_forward", "mlp_forward", "preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges",
+          "blend_forward", "blend_backward", "geom_backward", "mlp_backward", "hexplane_backward")
+
+
+def deform_args(name: str):
+    """Shape-matched deformation configs: mutant-shaped for C1-C4, force_blend-shaped for C5."""
+    a = types.SimpleNamespace(
+        net_width=64, defor_depth=0, posebase_pe=10, scale_rotation_pe=2, opacity_pe=2, grid_pe=0, force_pe=2,
+        time_pe=2, bounds=1.6, multires=[1, 2], no_dx=False, no_ds=False, no_dr=False, no_do=True, no_dshs=False,
+        empty_voxel=False, static_mlp=False, apply_rotation=True, use_time=True, use_force=False,
+        blend_time_force=True, prev_frames=0, no_grid=False,
+        kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
+                        "resolution": [64, 64, 64, 75]})
+    if name in ("C3", "C4"):
+        a.kplanes_config["resolution"] = [64, 64, 64, 150]
+    if name == "C5":
+        a.kplanes_config.update(output_coordinate_dim=128, resolution=[64, 64, 64, 256])
+        a.defor_depth, a.force_pe, a.time_pe, a.use_force = 5, 4, 4, True
+    return a
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="C2")
+    ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (then the line is not the headline config)")
+    ap.add_argument("--mode", default="train", choices=["train", "fps"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    syn = importlib.import_module("4dgaussians_amd.synthetic")
+    R = importlib.import_module("4dgaussians_amd.renderer")
+    Dm = importlib.import_module("4dgaussians_amd.scene.deformation")
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    cabi = importlib.import_module("4dgaussians_amd._cabi")
+    L = cabi.lib()
+
+    cfg = syn.CONFIGS[args.config]
+    _, cam0, raw = syn.make_workload(args.config, P=args.P)
+    P = raw["xyz"].shape[0]
+    W, H = cfg["W"], cfg["H"]
+    torch.manual_seed(syn.seed_for(args.config))
+    pc = R.GaussianParams(raw, dev)
+    deform = Dm.deform_network(deform_args(args.config))
+    deform.deformation_net.set_aabb([1.3, 1.3, 1.3], [-1.3, -1.3, -1.3])
+    deform = deform.to(dev)
+    if world > 1:  # replicas start identical
+        for p in list(pc.parameters()) + list(deform.parameters()):
+            dist.broadcast(p.data, 0)
+    # each rank looks at the scene from its own azimuth / timestamp (view-parallel)
+    rng = np.random.default_rng(1234 + rank)
+    cam_np = syn.look_at_camera(W, H, azimuth=0.7 + 0.6 * rank)
+    cam = R.Camera(cam_np, dev, time=float(rng.uniform(0, 1)), force=0.0)
+    bg = torch.ones(3, device=dev)
+    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank))
+    gauss_bucket = par.GradBucket(pc.parameters())
+    deform_bucket = par.GradBucket(deform.parameters())
+    all_params = list(pc.parameters()) + list(deform.parameters())
+
+    def train_step():
+        image, *_ = R.render(cam, pc, deform, bg)
+        loss = (image - target).abs().mean() / world     # SUM over ranks == mean over the global batch
+        loss.backward()
+        if world > 1:
+            gauss_bucket.all_reduce(async_op=True)        # overlaps with packing the second bucket
+            deform_bucket.all_reduce(async_op=True)
+            gauss_bucket.finish()
+            deform_bucket.finish()
+        for p in all_params:
+            p.grad = None
+
+    def fps_step():
+        R.render_for_image(cam, pc, deform, bg)
+
+    step = train_step if args.mode == "train" else fps_step
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    L.gs4d_profile_reset()
+    L.gs4d_profile_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    L.gs4d_profile_enable(0)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-stage device time from the HIP events recorded in the timed region
+    stages = {}
+    for s in STAGES:
+        ms, calls = C.c_double(0), C.c_long(0)
+        L.gs4d_profile_read(s.encode(), C.byref(ms), C.byref(calls))
+        if calls.value:
+            stages[s] = ms.value / calls.value
+
+    if rank == 0:
+        # workload statistics for the roofline numerators (one extra untimed forward through the C-level API)
+        with torch.no_grad():
+            m3, sc, rot, op, sh = deform.forward_dynamic(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features,
+                                                         torch.full((P, 1), cam.time, device=dev),
+                                                         torch.zeros(P, 1, device=dev), None)
+            Craw = importlib.import_module("4dgaussians_amd.diff_gaussian_rasterization")._C
+            e = torch.Tensor([])
+            Rn, _, _, radii, gb, bb, ib = Craw.rasterize_gaussians(
+                bg, m3, e, torch.sigmoid(op), torch.exp(sc), torch.nn.functional.normalize(rot), 1.0, e,
+                cam.world_view_transform, cam.full_proj_transform, cam_np.tanfovx, cam_np.tanfovy, H, W, sh, 3,
+                cam.camera_center, False, False)
+            view = Craw.state_view(P, Rn, W, H, gb, bb, ib)
+            nc = view["n_contrib"].to(torch.int64)
+            gy, gx = (H + 15) // 16, (W + 15) // 16
+            pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=dev)
+            pad[:H, :W] = nc
+            tile_max = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
+            pairs_bwd = int(tile_max.sum().item()) * 256        # (pixel, Gaussian) pairs the backward evaluates
+        roofline = None
+        if args.mode == "train" and "blend_backward" in stages:
+            # 44 B/instance staged + 40 B/instance gradient rows + 24 B/pixel (dL/dcolor 12, dL/ddepth 4, final_T 4, n_contrib 4)
+            alg_bytes = 84.0 * Rn + 24.0 * W * H
+            sec = stages["blend_backward"] * 1e-3
+            achieved = alg_bytes / sec / 1e9
+            roofline = {"kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_ms": round(stages["blend_backward"], 4), "algorithmic_bytes": alg_bytes,
+                        "note": "kernel is fp32-VALU/LDS bound, not HBM bound: see valu_* fields",
+                        "valu_pairs": pairs_bwd, "valu_flop_per_pair": 60,
+                        "valu_achieved_tflops": round(pairs_bwd * 60 / sec / 1e12, 3), "valu_peak_tflops": FP32_PEAK_TFLOPS,
+                        "valu_frac": round(pairs_bwd * 60 / sec / 1e12 / FP32_PEAK_TFLOPS, 4)}
+        elif "blend_forward" in stages:
+            alg_bytes = 44.0 * Rn + 24.0 * W * H
+            sec = stages["blend_forward"] * 1e-3
+            achieved = alg_bytes / sec / 1e9
+            roofline = {"kernel": "blend_forward_kernel", "bound": "hbm", "achieved": round(achieved, 2),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "avg_launch_ms": round(stages["blend_forward"], 4), "algorithmic_bytes": alg_bytes}
+
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(args, syn, raw, cam_np, cam.time, deform, target.cpu().numpy())
+
+        unit = "view-iterations/s (fwd+bwd)" if args.mode == "train" else "frames/s"
+        metric = "train iters/sec (fwd+bwd)" if args.mode == "train" else "render FPS"
+        out = {
+            "metric": metric, "value": round(world * args.steps / dt, 3), "unit": unit, "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}: {W}x{H}, P={P} Gaussians, SH degree 3, "
+                                   f"{'mutant' if args.config != 'C5' else 'force_blend'}-shaped HexPlane deformation, "
+                                   f"1 view per GPU per step", "global_batch_views": world,
+                       "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
+                       "grad_allreduce_bytes": gauss_bucket.nbytes + deform_bucket.nbytes},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, syn, raw, cam_np, t_view, deform, target):
+    """The CPU oracle on ONE core: PyTorch-CPU deformation restatement + scalar C rasterizer, one full
+    iteration of the same workload (forward only for --mode fps).  Reported, never used as the product."""
+    from oracle import deformation_ref as DR
+    from oracle import rasterizer_oracle as RO
+    torch.set_num_threads(1)
+    a = deform.deformation_net.args
+    kc = a.kplanes_config
+    cfg = DR.DeformConfig(net_width=a.net_width, defor_depth=a.defor_depth, posebase_pe=a.posebase_pe,
+                          scale_rotation_pe=a.scale_rotation_pe, force_pe=a.force_pe, time_pe=a.time_pe,
+                          plane_channels=kc["output_coordinate_dim"], resolution=list(kc["resolution"]),
+                          multires=list(a.multires), use_time=a.use_time, use_force=a.use_force)
+    train = args.mode == "train"
+    sd = {k: v.detach().cpu().contiguous().requires_grad_(train and v.dtype == torch.float32 and "poc" not in k and "aabb" not in k)
+          for k, v in deform.state_dict().items()}
+    P = raw["xyz"].shape[0]
+    x = {k: torch.from_numpy(raw[k]).requires_grad_(train) for k in ("xyz", "log_scales", "rot", "opacity_logit", "sh")}
+    t0 = time.perf_counter()
+    with torch.set_grad_enabled(train):
+        m3, sc, rot, op, sh = DR.forward_dynamic(sd, cfg, x["xyz"], x["log_scales"], x["rot"], x["opacity_logit"], x["sh"],
+                                                 torch.full((P, 1), float(t_view)), torch.zeros(P, 1))
+        sc_a, rot_a, op_a = torch.exp(sc), torch.nn.functional.normalize(rot), torch.sigmoid(op)
+    f = RO.forward(np.ones(3, np.float32), m3.detach().numpy(), None, op_a.detach().numpy(), sc_a.detach().numpy(),
+                   rot_a.detach().numpy(), 1.0, None, cam_np.viewmatrix, cam_np.projmatrix, cam_np.tanfovx, cam_np.tanfovy,
+                   cam_np.image_height, cam_np.image_width, sh.detach().numpy(), 3, cam_np.campos)
+    if train:
+        gc = (np.sign(f["color"] - target) / target.size).astype(np.float32)
+        g = RO.backward(f, gc, np.zeros((1, cam_np.image_height, cam_np.image_width), np.float32))
+        tg = lambda k, shape: torch.from_numpy(g[k].reshape(shape))
+        torch.autograd.backward([m3, sc_a, rot_a, op_a, sh],
+                                [tg("dL_dmeans3D", m3.shape), tg("dL_dscales", sc_a.shape), tg("dL_drotations", rot_a.shape),
+                                 tg("dL_dopacity", op_a.shape), tg("dL_dsh", sh.shape)])
+    sec = time.perf_counter() - t0
+    return {"value": round(1.0 / sec, 5), "unit": "view-iterations/s (fwd+bwd)" if train else "frames/s", "cores": 1,
+            "kind": "port", "seconds": round(sec, 2),
+            "sample": f"one full {'fwd+bwd iteration' if train else 'frame'} of the same workload (P={P}, "
+                      f"{cam_np.image_width}x{cam_np.image_height}) on 1 thread: oracle/deformation_ref.py + oracle/rasterizer_ref.c"}
+
+
+if __name__ == "__main__":
+    main()

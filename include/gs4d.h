@@ -45,6 +45,18 @@ const char* gs4d_last_error(void);
 int gs4d_abi_version(void);
 
 /*
+ * Per-stage device timing, for bench.py's roofline figures (no counterpart in the reference, which
+ * has no profiling hooks).  While enabled, every kernel stage is bracketed by HIP events on the
+ * stream it is launched on; gs4d_profile_read() waits for the recorded events and returns the
+ * accumulated milliseconds and launch count of one stage ("preprocess", "scan", "emit_keys",
+ * "radix_sort", "tile_ranges", "blend_forward", "blend_backward", "geom_backward",
+ * "hexplane_forward", "hexplane_backward", "mlp_forward", "mlp_backward", "knn").
+ */
+void gs4d_profile_enable(int on);
+void gs4d_profile_reset(void);
+int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
+
+/*
  * Forward render.  Replaces Rasterizer::forward (rasterizer.h:31-54; implementation
  * rasterizer_impl.cu:198-339).  Argument meaning is identical:
  *   P Gaussians, D active SH degree, M SH coefficients per Gaussian (0 if shs == NULL);
