@@ -23,7 +23,7 @@
 //    fmaf chain, so parity with the fp32 reference holds to ~1e-6), operands staged through LDS
 //    with a 33-float row pitch (conflict-free ds_read_b32 for the A fragment);
 //  * weight gradients reduce over the points with the same MFMA (K = points), one partial slab
-//    per 1024-point chunk and a fixed-order slab sum (deterministic); plane gradients use float
+//    per 512-point chunk and a fixed-order slab sum (deterministic); plane gradients use float
 //    atomics (the only non-deterministic sums in the library).
 #include "gs4d_internal.h"
 
@@ -31,7 +31,7 @@
 #define NHEAD 4             // pos, scales, rotations, shs
 #define OUT_LD 64           // row pitch of the heads' raw output matrix O
 #define ROWS_PER_WG 128
-#define DW_ROWS_PER_WG 1024
+#define DW_ROWS_PER_WG 512
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -343,75 +343,134 @@ struct GemmJob {
 };
 struct GemmJobs { GemmJob j[8]; };
 
-#define KCH 32   // K chunk staged per step
+#define KCH 32        // K chunk staged per step
+#define SB_PITCH 65   // row pitch of the staged B operand: conflict-free for both the transposing store and the fragment read
+// Pipeline per 32-wide K chunk: the next chunk's 128x32 A tile is fetched into registers (16 independent
+// coalesced loads per lane, all issued before the MFMAs), the MFMAs run on the current LDS buffer, then the
+// registers are written to the other LDS buffer; one barrier per chunk.
 __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 {
     extern __shared__ float smem[];
     const GemmJob& J = jobs.j[blockIdx.y];
     const int Kpad = (J.K + KCH - 1) / KCH * KCH;
-    float* sB = smem;                       // [Kpad][64]
-    float* sA = smem + (size_t)Kpad * 64;   // [128][33]
+    float* sB = smem;                                   // [Kpad][SB_PITCH]
+    float* sA = smem + (size_t)Kpad * SB_PITCH;         // 2 x [128][33]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int row0 = blockIdx.x * ROWS_PER_WG;
 
-    // stage B (zero padded to 64 columns and Kpad rows)
-    for (int i = tid; i < Kpad * 64; i += 256) {
-        const int k = i >> 6, j = i & 63;
-        float v = 0.f;
-        if (k < J.K && j < J.N) {
-            int kl = k, s = 0;
-            while (s < J.b_nseg - 1 && kl >= J.b_rows[s]) { kl -= J.b_rows[s]; s++; }
-            v = J.b_transposed ? J.B[s][(size_t)(J.b_col0[s] + j) * J.b_ld[s] + kl]
-                               : J.B[s][(size_t)kl * J.b_ld[s] + J.b_col0[s] + j];
+    // stage B, reading along the source's contiguous axis; loads are unconditional (clamped address,
+    // value selected afterwards) and issued eight at a time so their latencies overlap
+    if (J.b_transposed) {
+        for (int k = tid & 31; k < Kpad; k += 32) {
+            int kl = min(k, J.K - 1), sg = 0;
+            while (sg < J.b_nseg - 1 && kl >= J.b_rows[sg]) { kl -= J.b_rows[sg]; sg++; }
+            const float* src = J.B[sg] + (size_t)J.b_col0[sg] * J.b_ld[sg] + kl;
+            const int ld = J.b_ld[sg];
+            float v[8];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int j = (tid >> 5) + 8 * jj;
+                v[jj] = src[(size_t)min(j, J.N - 1) * ld];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int j = (tid >> 5) + 8 * jj;
+                sB[k * SB_PITCH + j] = (k < J.K && j < J.N) ? v[jj] : 0.f;
+            }
         }
-        sB[i] = v;
+    } else {
+        const int j = tid & 63;
+        const int jc = min(j, J.N - 1);
+        for (int kb = tid >> 6; kb < Kpad; kb += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = kb + 4 * u;
+                int kl = min(k, J.K - 1), sg = 0;
+                while (sg < J.b_nseg - 1 && kl >= J.b_rows[sg]) { kl -= J.b_rows[sg]; sg++; }
+                v[u] = J.B[sg][(size_t)kl * J.b_ld[sg] + J.b_col0[sg] + jc];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = kb + 4 * u;
+                if (k < Kpad) sB[k * SB_PITCH + j] = (k < J.K && j < J.N) ? v[u] : 0.f;
+            }
+        }
     }
+
+    const int kk_l = tid & 31, r_l = tid >> 5;          // this lane stages column kk_l of rows r_l + 8n
+    float nxt[16];
+    int nxt_k = 0;
+    auto fetch = [&](int k0) {
+        const int k = k0 + kk_l;
+        int kl = min(k, J.K - 1), sg = 0;
+        while (sg < J.a_nseg - 1 && kl >= J.a_len[sg]) { kl -= J.a_len[sg]; sg++; }
+        // unconditional loads from clamped addresses (out-of-range rows / columns are zeroed in stash()):
+        // no branches and no ALU use of the loaded values before the MFMAs
+        const float* src = J.A + J.a_beg[sg] + kl;
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            const int row = min(row0 + r_l + 8 * n, P - 1);
+            nxt[n] = src[(size_t)row * J.lda];
+        }
+        nxt_k = k;
+    };
+    auto stash = [&](float* buf) {
+#pragma unroll
+        for (int n = 0; n < 16; n++) {
+            float v = (nxt_k < J.K && row0 + r_l + 8 * n < P) ? nxt[n] : 0.f;
+            if (J.relu_a) v = fmaxf(v, 0.f);
+            buf[(r_l + 8 * n) * 33 + kk_l] = v;
+        }
+    };
 
     f32x16 acc0 = {0}, acc1 = {0};
     const bool two = J.N > 32;
     const int arow = wave * 32 + (lane & 31);
     const int khalf = lane >> 5;
-    for (int k0 = 0; k0 < Kpad; k0 += KCH) {
-        __syncthreads();
-        // stage A chunk: 128 rows x 32 columns
-#pragma unroll 4
-        for (int i = tid; i < ROWS_PER_WG * KCH; i += 256) {
-            const int r = i >> 5, kk = i & 31;
-            const int k = k0 + kk, row = row0 + r;
-            float v = 0.f;
-            if (k < J.K && row < P) {
-                int kl = k, s = 0;
-                while (s < J.a_nseg - 1 && kl >= J.a_len[s]) { kl -= J.a_len[s]; s++; }
-                v = J.A[(size_t)row * J.lda + J.a_beg[s] + kl];
-                if (J.relu_a) v = fmaxf(v, 0.f);
-            }
-            sA[r * 33 + kk] = v;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kk = 0; kk < KCH; kk += 2) {
-            const float a = sA[arow * 33 + kk + khalf];
-            const float b0 = sB[(k0 + kk + khalf) * 64 + (lane & 31)];
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            if (two) {
-                const float b1 = sB[(k0 + kk + khalf) * 64 + 32 + (lane & 31)];
+    const int nchunks = Kpad / KCH;
+    fetch(0);
+    stash(sA);
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const float* cur = sA + (c & 1) * (ROWS_PER_WG * 33);
+        if (c + 1 < nchunks) fetch((c + 1) * KCH);
+        const float* bcur = sB + (size_t)(c * KCH + khalf) * SB_PITCH + (lane & 31);
+        if (two) {
+#pragma unroll
+            for (int kk = 0; kk < KCH; kk += 2) {
+                const float a = cur[arow * 33 + kk + khalf];
+                const float b0 = bcur[kk * SB_PITCH];
+                const float b1 = bcur[kk * SB_PITCH + 32];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
             }
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < KCH; kk += 2) {
+                const float a = cur[arow * 33 + kk + khalf];
+                const float b0 = bcur[kk * SB_PITCH];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            }
         }
+        if (c + 1 < nchunks) stash(sA + ((c + 1) & 1) * (ROWS_PER_WG * 33));
+        __syncthreads();
     }
     // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
     const int col = lane & 31;
+    const float bias0 = (J.bias && col < J.N) ? J.bias[col] : 0.f;
+    const float bias1 = (J.bias && col + 32 < J.N) ? J.bias[col + 32] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
         const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (row >= P) continue;
         if (col < J.N) {
-            float v = acc0[r] + (J.bias ? J.bias[col] : 0.f);
+            float v = acc0[r] + bias0;
             if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col] > 0.f)) v = 0.f;
             J.Y[(size_t)row * J.ldy + J.ycol0 + col] = v;
         }
         if (two && col + 32 < J.N) {
-            float v = acc1[r] + (J.bias ? J.bias[col + 32] : 0.f);
+            float v = acc1[r] + bias1;
             if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col + 32] > 0.f)) v = 0.f;
             J.Y[(size_t)row * J.ldy + J.ycol0 + col + 32] = v;
         }
@@ -428,6 +487,10 @@ struct DwJob {
 };
 struct DwJobs { DwJob j[16]; };
 
+// Each wave owns one 32-row block of n and three 32-column blocks of k; per step it fetches 16 point rows
+// (8 MFMA k-steps) of its G and X columns straight from global memory -- every load is a coalesced
+// 128-byte row segment per half-wave -- one step ahead of the MFMAs that consume them.
+#define DW_STEP 8   // MFMA k-steps (pairs of point rows) per register block
 __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
 {
     const DwJob& J = jobs.j[blockIdx.y];
@@ -438,33 +501,47 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     const int rbeg = blockIdx.x * DW_ROWS_PER_WG, rend = min(P, rbeg + DW_ROWS_PER_WG);
     const int n = nblk * 32 + (lane & 31);
     const int half = lane >> 5;
-    int xcol[3]; bool xone[3], xok[3];
+    const bool nok = n < J.N;
+    const float* gsrc = J.G + J.gcol0 + min(n, J.N - 1);
+    const float* xsrc[3]; bool xone[3], xok[3];
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int k = (kb0 + 2 * t) * 32 + (lane & 31);
         xone[t] = (k == J.K);
         xok[t] = (kb0 + 2 * t) < J.kblocks && k < J.K;
-        int kl = k, s = 0;
+        int kl = min(k, J.K - 1), s = 0;
         while (s < J.x_nseg - 1 && kl >= J.x_len[s]) { kl -= J.x_len[s]; s++; }
-        xcol[t] = J.x_beg[s] + kl;
+        xsrc[t] = J.X + J.x_beg[s] + kl;
     }
-    f32x16 acc[3] = {{0}, {0}, {0}};
-#pragma unroll 4
-    for (int r = rbeg; r < rend; r += 2) {
-        const int row = r + half;
-        const bool ok = row < rend;
-        const float a = (ok && n < J.N) ? J.G[(size_t)row * J.ldg + J.gcol0 + n] : 0.f;
+    float a_n[DW_STEP], b_n[3][DW_STEP];
+    auto fetch = [&](int r) {
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            float b = 0.f;
-            if (ok) {
-                if (xok[t]) {
-                    b = J.X[(size_t)row * J.ldx + xcol[t]];
-                    if (J.relu_x) b = fmaxf(b, 0.f);
-                } else if (xone[t]) b = 1.f;
-            }
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[t], 0, 0, 0);
+        for (int s = 0; s < DW_STEP; s++) {
+            const int row = min(r + 2 * s + half, rend - 1);      // clamped: validity is applied at consumption
+            a_n[s] = gsrc[(size_t)row * J.ldg];
+#pragma unroll
+            for (int t = 0; t < 3; t++) b_n[t][s] = xsrc[t][(size_t)row * J.ldx];
         }
+    };
+    f32x16 acc[3] = {{0}, {0}, {0}};
+    fetch(rbeg);
+    for (int r = rbeg; r < rend; r += 2 * DW_STEP) {
+        float a_c[DW_STEP], b_c[3][DW_STEP];
+#pragma unroll
+        for (int s = 0; s < DW_STEP; s++) {
+            const bool ok = r + 2 * s + half < rend;
+            a_c[s] = (ok && nok) ? a_n[s] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                float b = xok[t] ? (J.relu_x ? fmaxf(b_n[t][s], 0.f) : b_n[t][s]) : (xone[t] ? 1.f : 0.f);
+                b_c[t][s] = ok ? b : 0.f;
+            }
+        }
+        if (r + 2 * DW_STEP < rend) fetch(r + 2 * DW_STEP);
+#pragma unroll
+        for (int s = 0; s < DW_STEP; s++)
+#pragma unroll
+            for (int t = 0; t < 3; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[s], b_c[t][s], acc[t], 0, 0, 0);
     }
     const int pitch = 32 * J.kblocks;
     float* slab = J.slabs + (size_t)blockIdx.x * 64 * pitch;
@@ -646,7 +723,7 @@ static int validate(const gs4d_deform_desc* d, int P)
     return GS4D_OK;
 }
 
-static size_t gemm_lds_bytes(int K) { return ((size_t)((K + KCH - 1) / KCH * KCH) * 64 + (size_t)ROWS_PER_WG * 33) * sizeof(float); }
+static size_t gemm_lds_bytes(int K) { return ((size_t)((K + KCH - 1) / KCH * KCH) * SB_PITCH + (size_t)2 * ROWS_PER_WG * 33) * sizeof(float); }
 
 static int launch_gemm(int P, GemmJobs& jobs, int njobs, hipStream_t s)
 {
