@@ -35,7 +35,8 @@ def lib() -> C.CDLL:
                 "(or python -c 'import __graft_entry__ as g; g.build()'). There is no CPU/PyTorch fallback.")
         L = C.CDLL(LIB_PATH)
         L.gs4d_last_error.restype = C.c_char_p
-        for name in ("gs4d_geometry_bytes", "gs4d_binning_bytes", "gs4d_image_bytes", "gs4d_backward_scratch_bytes"):
+        for name in ("gs4d_geometry_bytes", "gs4d_binning_bytes", "gs4d_image_bytes", "gs4d_backward_scratch_bytes",
+                     "gs4d_l1_loss_scratch_bytes"):
             getattr(L, name).restype = C.c_size_t
         _lib = L
     return _lib
@@ -77,3 +78,32 @@ class TensorAllocator:
                 return 0
 
         self.callback = ALLOC_FN(_alloc)
+
+
+def empty_group(device, *shapes):
+    """Uninitialised float32 tensors carved out of one allocation (see zeros_group)."""
+    return zeros_group(device, *shapes, _fill=False)
+
+
+def zeros_group(device, *shapes, dtypes=None, _fill=True):
+    """Several zero-initialised 4-byte-element tensors carved out of ONE allocation cleared by ONE
+    fill (each a 256-byte aligned view): dozens of separate torch.zeros calls cost more host and
+    launch-gap time per training step than the kernels that consume them."""
+    counts = []
+    for shp in shapes:
+        n = 1
+        for d in shp:
+            n *= int(d)
+        counts.append(n)
+    offs, total = [], 0
+    for n in counts:
+        offs.append(total)
+        total += (n + 63) // 64 * 64
+    flat = (torch.zeros if _fill else torch.empty)(max(total, 1), dtype=torch.float32, device=device)
+    out = []
+    for i, (shp, n, o) in enumerate(zip(shapes, counts, offs)):
+        t = flat[o:o + n]
+        if dtypes is not None and dtypes[i] is not torch.float32:
+            t = t.view(dtypes[i])
+        out.append(t.view(*shp))
+    return out

@@ -38,9 +38,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if device.type != "cuda":
         raise RuntimeError("rasterize_gaussians needs tensors on a HIP device; there is no CPU path")
     P, H, W = means3D.size(0), int(image_height), int(image_width)
-    out_color = torch.zeros((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
-    out_depth = torch.zeros((1, H, W), dtype=torch.float32, device=device)
-    radii = torch.zeros((P,), dtype=torch.int32, device=device)
+    out_color, out_depth, radii = _cabi.zeros_group(device, (NUM_CHANNELS, H, W), (1, H, W), (P,),
+                                                    dtypes=(torch.float32, torch.float32, torch.int32))
     geom, binning, img = (_cabi.TensorAllocator(device) for _ in range(3))
     rendered = C.c_int(0)
     if P != 0:
@@ -73,10 +72,9 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
-    z = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=device)
-    dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths = z(P, 3), z(P, 3), z(P, NUM_CHANNELS), z(P, 1)
-    dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh = z(P, 2, 2), z(P, 1), z(P, 6), z(P, M, 3)
-    dL_dscales, dL_drotations = z(P, 3), z(P, 4)
+    (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales,
+     dL_drotations) = _cabi.zeros_group(device, (P, 3), (P, 3), (P, NUM_CHANNELS), (P, 1), (P, 2, 2), (P, 1), (P, 6),
+                                        (P, M, 3), (P, 3), (P, 4))
     if P != 0:
         keep = [_dev_f32(t, device) for t in (background, means3D, sh, colors, scales, rotations, cov3D_precomp,
                                                 viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_depth)]

@@ -16,6 +16,7 @@ import torch
 import torch.nn as nn
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from .fused import activate
 
 
 class GaussianParams(nn.Module):
@@ -62,9 +63,7 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
         force = torch.full((n, 1), cam.force, dtype=torch.float32, device=means3D.device)
         means3D, scales, rotations, opacity, shs = deform.forward_dynamic(means3D, scales, rotations, opacity, shs,
                                                                           time, force, None)
-    scales = torch.exp(scales)
-    rotations = torch.nn.functional.normalize(rotations)
-    opacity = torch.sigmoid(opacity)
+    scales, rotations, opacity = activate(scales, rotations, opacity)    # exp / L2-normalise / sigmoid, one kernel
     image, radii, depth = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
                                      opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
     return image, screenspace_points, radii > 0, radii, depth

@@ -124,11 +124,14 @@ class _DeformFunction(torch.autograd.Function):
         P = points_.shape[0]
         planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
         d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
-        zeros = lambda t, cl=False: torch.zeros_like(t, memory_format=torch.channels_last if cl else torch.contiguous_format)
-        gp = [zeros(p, True) for p in planes]
-        g_ftw, g_ftb = zeros(ft_w), zeros(ft_b)
-        gt = [zeros(t) for t in trunk]
-        gh = [zeros(t) for t in heads]
+        # every parameter gradient lives in one allocation cleared by one fill; plane gradients are
+        # channels-last like the planes themselves ([H][W][C] bytes under a [1,C,H,W] shape)
+        nhwc = [(1, p.shape[2], p.shape[3], p.shape[1]) for p in planes]
+        flat = _cabi.zeros_group(dev, *nhwc, ft_w.shape, ft_b.shape, *[t.shape for t in trunk], *[t.shape for t in heads])
+        gp = [t.permute(0, 3, 1, 2) for t in flat[:len(planes)]]
+        g_ftw, g_ftb = flat[len(planes)], flat[len(planes) + 1]
+        gt = flat[len(planes) + 2:len(planes) + 2 + len(trunk)]
+        gh = flat[len(planes) + 2 + len(trunk):]
         g = DeformGrads()
         for i, t in enumerate(gp):
             g.planes[i] = t.data_ptr()
@@ -138,7 +141,7 @@ class _DeformFunction(torch.autograd.Function):
         for h in range(4):
             g.head_w1[h], g.head_b1[h] = gh[4 * h].data_ptr(), gh[4 * h + 1].data_ptr()
             g.head_w2[h], g.head_b2[h] = gh[4 * h + 2].data_ptr(), gh[4 * h + 3].data_ptr()
-        gz = lambda t, like: (torch.zeros_like(like) if t is None else t.to(torch.float32).contiguous())
+        gz = lambda t, like: (torch.zeros_like(like) if t is None else (t if t.dtype == torch.float32 and t.is_contiguous() else t.to(torch.float32).contiguous()))
         g_xyz, g_sc, g_rot = gz(g_xyz, points_), gz(g_sc, scales_), gz(g_rot, rot_)
         g_shs = gz(g_shs, torch.empty(P, 16, 3, device=dev))
         if g_rot.data_ptr() % 16:

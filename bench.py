@@ -42,8 +42,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3   # vector / f32-MFMA peak
 
-STAGES = ("hexplane_forward", "mlp_forward", "preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges",
-          "blend_forward", "blend_backward", "geom_backward", "mlp_backward", "hexplane_backward")
+STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges",
+          "blend_forward", "l1_loss_forward", "l1_loss_backward", "blend_backward", "geom_backward",
+          "activate_backward", "mlp_backward", "hexplane_backward")
 
 
 def deform_args(name: str):
@@ -72,6 +73,8 @@ def main():
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (then the line is not the headline config)")
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true",
+                    help="do not record per-stage HIP events in the timed region (then no roofline / stages_ms)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -89,6 +92,7 @@ def main():
     R = importlib.import_module("4dgaussians_amd.renderer")
     Dm = importlib.import_module("4dgaussians_amd.scene.deformation")
     par = importlib.import_module("4dgaussians_amd.parallel")
+    F = importlib.import_module("4dgaussians_amd.fused")
     cabi = importlib.import_module("4dgaussians_amd._cabi")
     L = cabi.lib()
 
@@ -116,7 +120,7 @@ def main():
 
     def train_step():
         image, *_ = R.render(cam, pc, deform, bg)
-        loss = (image - target).abs().mean() / world     # SUM over ranks == mean over the global batch
+        loss = F.l1_loss(image, target) / world           # SUM over ranks == mean over the global batch
         loss.backward()
         if world > 1:
             gauss_bucket.all_reduce(async_op=True)        # overlaps with packing the second bucket
@@ -141,7 +145,7 @@ def main():
         step()
     sync()
     L.gs4d_profile_reset()
-    L.gs4d_profile_enable(1)
+    L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()

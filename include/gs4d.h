@@ -237,6 +237,24 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
                          float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in, float* dL_dshs_in,
                          char* workspace, char* scratch, void* stream);
 
+/* ---- activations + photometric loss (the framework ops between the three kernels groups) ----
+ * Replaces, for the hot path, the torch ops of scene/gaussian_model.py:38-43 applied at
+ * gaussian_renderer/renderer.py:170-172 (scales = exp, rotations = F.normalize, opacity = sigmoid)
+ * and utils/loss_utils.py:20-21 (l1_loss = mean |a - b|), each as one fused kernel per direction.
+ * rotations pointers must be 16-byte aligned.  Upstream gradients of the backward may be NULL
+ * (treated as zero).  The backward reads the forward OUTPUTS scales / opacity and the raw rotations. */
+int gs4d_activate_forward(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
+                          float* scales, float* rotations_n, float* opacity, void* stream);
+int gs4d_activate_backward(int P, const float* scales, const float* rotations, const float* opacity,
+                           const float* g_scales, const float* g_rotations_n, const float* g_opacity,
+                           float* d_log_scales, float* d_rotations, float* d_opacity_logit, void* stream);
+
+/* loss[0] = mean |a[i] - b[i]| over n floats (deterministic two-pass reduction; scratch of
+ * gs4d_l1_loss_scratch_bytes()); backward writes d_a[i] = sign(a[i]-b[i]) * g_loss[0] / n. */
+size_t gs4d_l1_loss_scratch_bytes(void);
+int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream);
+int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float* g_loss, float* d_a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
