@@ -4,7 +4,8 @@
 // Orchestration matched: RAST/cuda_rasterizer/rasterizer_impl.cu:198-339 (forward) and :343-444
 // (backward) of the reference, RAST = submodules/depth-diff-gaussian-rasterization.  Unlike the
 // reference, which launches on the legacy default stream, every launch goes to the stream the
-// caller passes, and no global mutable state is kept (one process per GPU stays independent).
+// caller passes.  The only global state is the opt-in stage timer below (off by default) and the
+// thread-local error string; one process per GPU stays independent.
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -30,6 +31,14 @@ namespace {
 struct ProfRec { std::string stage; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+std::string g_prof_only;                                // when non-empty: the only stage that records events
+std::vector<hipEvent_t> g_prof_pool;                    // resolved events, reused (event creation is slow)
+hipEvent_t prof_event_locked()
+{
+    hipEvent_t e = nullptr;
+    if (!g_prof_pool.empty()) { e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 std::vector<ProfRec> g_prof_open;                       // recorded, not yet resolved
 struct ProfSum { std::string stage; double ms; long calls; };
 std::vector<ProfSum> g_prof_sums;
@@ -43,8 +52,8 @@ void prof_resolve_locked()
                 if (s.stage == r.stage) { s.ms += ms; s.calls++; found = true; break; }
             if (!found) g_prof_sums.push_back({r.stage, ms, 1});
         }
-        (void)hipEventDestroy(r.a);
-        (void)hipEventDestroy(r.b);
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
     }
     g_prof_open.clear();
 }
@@ -54,10 +63,11 @@ Gs4dProfScope::Gs4dProfScope(const char* stage, hipStream_t s) : slot(-1), strea
 {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_only.empty() && g_prof_only != stage) return;
     ProfRec r;
     r.stage = stage;
-    if (hipEventCreate(&r.a) != hipSuccess) return;
-    if (hipEventCreate(&r.b) != hipSuccess) { (void)hipEventDestroy(r.a); return; }
+    if (!(r.a = prof_event_locked())) return;
+    if (!(r.b = prof_event_locked())) { g_prof_pool.push_back(r.a); return; }
     (void)hipEventRecord(r.a, s);
     g_prof_open.push_back(r);
     slot = (int)g_prof_open.size() - 1;
@@ -150,6 +160,12 @@ void gs4d_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+}
+
+void gs4d_profile_select(const char* stage)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_only = stage ? stage : "";
 }
 
 void gs4d_profile_reset(void)

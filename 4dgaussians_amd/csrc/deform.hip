@@ -32,6 +32,7 @@
 #define OUT_LD 64           // row pitch of the heads' raw output matrix O
 #define ROWS_PER_WG 128
 #define DW_ROWS_PER_WG 512
+#define STRIP_WGS 256           // point runs of the time-plane strip kernel (x3 planes)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -111,6 +112,7 @@ __device__ __constant__ const int kPairA[6] = {0, 0, 0, 1, 1, 2};
 __device__ __constant__ const int kPairB[6] = {1, 2, 3, 2, 3, 3};
 
 struct Corner {
+    int x0, x1, y0, y1;          // texel coordinates of the four corners
     int i00, i01, i10, i11;      // texel indices (y*W + x)
     float w00, w01, w10, w11;
     float wx, wy;                // fractional parts
@@ -131,6 +133,7 @@ __device__ __forceinline__ Corner corner_of(float u, float v, int Ww, int Hh)
     c.wy = y - y0;
     const int x0i = (int)x0, y0i = (int)y0;
     const int x1i = min(x0i + 1, Ww - 1), y1i = min(y0i + 1, Hh - 1);
+    c.x0 = x0i; c.x1 = x1i; c.y0 = y0i; c.y1 = y1i;
     c.i00 = y0i * Ww + x0i; c.i01 = y0i * Ww + x1i;
     c.i10 = y1i * Ww + x0i; c.i11 = y1i * Ww + x1i;
     c.w00 = (1.f - c.wx) * (1.f - c.wy); c.w01 = c.wx * (1.f - c.wy);
@@ -186,12 +189,47 @@ __global__ __launch_bounds__(256) void hexplane_forward_kernel(
     }
 }
 
-// Backward: one lane per channel (C lanes per point, C <= 64; for C > 64 a lane loops), so each
-// atomic wave-instruction covers whole contiguous channel rows.  Also produces d/d(xyz) and d/d(t').
-__global__ __launch_bounds__(256) void hexplane_backward_kernel(
+// Backward, common part: for one (point, level, channel) sample the six planes and return
+// gi[i] = dL/dfeat * product of the other five samples, plus the coordinate derivatives.
+struct SixSamples { float gi[6], ddx[6], ddy[6]; };
+
+__device__ __forceinline__ SixSamples six_samples(const PlaneTable& T, int l, int C, int ch, const Corner cn[6], float g)
+{
+    SixSamples o;
+    float v[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const float* __restrict__ base = T.p[l * 6 + i] + ch;
+        const float f00 = base[(size_t)cn[i].i00 * C], f01 = base[(size_t)cn[i].i01 * C];
+        const float f10 = base[(size_t)cn[i].i10 * C], f11 = base[(size_t)cn[i].i11 * C];
+        v[i] = f00 * cn[i].w00 + f01 * cn[i].w01 + f10 * cn[i].w10 + f11 * cn[i].w11;
+        o.ddx[i] = ((f01 - f00) * (1.f - cn[i].wy) + (f11 - f10) * cn[i].wy) * cn[i].sx;
+        o.ddy[i] = ((f10 - f00) * (1.f - cn[i].wx) + (f11 - f01) * cn[i].wx) * cn[i].sy;
+    }
+    // product of the other five planes via prefix / suffix products (no division)
+    float pre[6], suf[6];
+    pre[0] = 1.f;
+#pragma unroll
+    for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * v[i - 1];
+    suf[5] = 1.f;
+#pragma unroll
+    for (int i = 4; i >= 0; i--) suf[i] = suf[i + 1] * v[i + 1];
+#pragma unroll
+    for (int i = 0; i < 6; i++) o.gi[i] = g * pre[i] * suf[i];
+    return o;
+}
+
+__device__ __constant__ const int kSpatial[3] = {0, 1, 3};
+__device__ __constant__ const int kTimeP[3] = {2, 4, 5};
+
+// Backward, spatial planes (xy, xz, yz) and the coordinate gradients: one lane per channel (C lanes per
+// point, C <= 64; for C > 64 a lane loops), so each atomic wave-instruction covers whole contiguous
+// channel rows (128-B segments: the full-rate shape for memory-side float atomics).
+__global__ __launch_bounds__(256) void hexplane_backward_spatial_kernel(
     int P, int C, int L, int lanes_shift, PlaneTable T, const float* __restrict__ aabb,
     const float* __restrict__ xyz, const float* __restrict__ tprime, const float* __restrict__ dfeat, int ldf,
-    float* __restrict__ dxyz, float* __restrict__ dtprime)
+    float4* __restrict__ dcoord,               // [P]: (d/dx, d/dy, d/dz, d/dt') in normalised coordinates
+    float* __restrict__ gtime)                 // [P][L][3][C]: dL/d(sample) of the three time planes, for the strip kernel
 {
     const int lanes = 1 << lanes_shift;                 // lanes per point = min(C, 64)
     const int gtid = blockIdx.x * 256 + threadIdx.x;
@@ -213,37 +251,22 @@ __global__ __launch_bounds__(256) void hexplane_backward_kernel(
 #pragma unroll
         for (int i = 0; i < 6; i++) cn[i] = corner_of(pts[kPairA[i]], pts[kPairB[i]], T.w[l * 6 + i], T.h[l * 6 + i]);
         for (int ch = sub; ch < C; ch += lanes) {
-            float v[6], ddx[6], ddy[6];
-            if (live) {
+            if (!live) continue;
+            const SixSamples q = six_samples(T, l, C, ch, cn, dfeat[(size_t)p * ldf + l * C + ch]);
 #pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const float* __restrict__ base = T.p[l * 6 + i] + ch;
-                    const float f00 = base[(size_t)cn[i].i00 * C], f01 = base[(size_t)cn[i].i01 * C];
-                    const float f10 = base[(size_t)cn[i].i10 * C], f11 = base[(size_t)cn[i].i11 * C];
-                    v[i] = f00 * cn[i].w00 + f01 * cn[i].w01 + f10 * cn[i].w10 + f11 * cn[i].w11;
-                    ddx[i] = ((f01 - f00) * (1.f - cn[i].wy) + (f11 - f10) * cn[i].wy) * cn[i].sx;
-                    ddy[i] = ((f10 - f00) * (1.f - cn[i].wx) + (f11 - f01) * cn[i].wx) * cn[i].sy;
-                }
-                const float g = dfeat[(size_t)p * ldf + l * C + ch];
-                // product of the other five planes via prefix / suffix products (no division)
-                float pre[6], suf[6];
-                pre[0] = 1.f;
+            for (int j = 0; j < 3; j++) {
+                const int i = kSpatial[j];
+                float* __restrict__ gb = T.g[l * 6 + i] + ch;
+                unsafeAtomicAdd(gb + (size_t)cn[i].i00 * C, q.gi[i] * cn[i].w00);
+                unsafeAtomicAdd(gb + (size_t)cn[i].i01 * C, q.gi[i] * cn[i].w01);
+                unsafeAtomicAdd(gb + (size_t)cn[i].i10 * C, q.gi[i] * cn[i].w10);
+                unsafeAtomicAdd(gb + (size_t)cn[i].i11 * C, q.gi[i] * cn[i].w11);
+                gtime[(((size_t)p * L + l) * 3 + j) * C + ch] = q.gi[kTimeP[j]];
+            }
 #pragma unroll
-                for (int i = 1; i < 6; i++) pre[i] = pre[i - 1] * v[i - 1];
-                suf[5] = 1.f;
-#pragma unroll
-                for (int i = 4; i >= 0; i--) suf[i] = suf[i + 1] * v[i + 1];
-#pragma unroll
-                for (int i = 0; i < 6; i++) {
-                    const float gi = g * pre[i] * suf[i];
-                    float* __restrict__ gb = T.g[l * 6 + i] + ch;
-                    unsafeAtomicAdd(gb + (size_t)cn[i].i00 * C, gi * cn[i].w00);
-                    unsafeAtomicAdd(gb + (size_t)cn[i].i01 * C, gi * cn[i].w01);
-                    unsafeAtomicAdd(gb + (size_t)cn[i].i10 * C, gi * cn[i].w10);
-                    unsafeAtomicAdd(gb + (size_t)cn[i].i11 * C, gi * cn[i].w11);
-                    dpts[kPairA[i]] += gi * ddx[i];
-                    dpts[kPairB[i]] += gi * ddy[i];
-                }
+            for (int i = 0; i < 6; i++) {
+                dpts[kPairA[i]] += q.gi[i] * q.ddx[i];
+                dpts[kPairB[i]] += q.gi[i] * q.ddy[i];
             }
         }
     }
@@ -251,14 +274,209 @@ __global__ __launch_bounds__(256) void hexplane_backward_kernel(
 #pragma unroll
     for (int a = 0; a < 4; a++)
         for (int off = lanes >> 1; off >= 1; off >>= 1) dpts[a] += __shfl_xor(dpts[a], off, 64);
-    if (live && sub == 0) {
+    if (live && sub == 0) dcoord[p] = make_float4(dpts[0], dpts[1], dpts[2], dpts[3]);
+}
+
+// Backward, time planes (xt, yt, zt).  All Gaussians of a view share one timestamp, so their time-plane
+// gradients land in just two texel rows per plane; adding them with memory-side atomics means ~P*4 adds
+// per plane contending for a few hundred rows (an order of magnitude below the atomic rate), and LDS
+// float atomics (ds_add_f32) measured ~0.3 lanes/clk here.  Instead the two rows are computed as a small
+// dense product on the f32 matrix cores:
+//     strip[r][x][ch] = sum_p  Wgt_r[x][p] * G[p][ch],   Wgt_r[x][p] = bilinear weight of point p at (row r, column x)
+// with K = the points of the wave's run (two per v_mfma_f32_32x32x2_f32), one 32-column bucket of x per
+// accumulator tile.  The A operand is built in registers from the point's corner (4 non-zeros per point), the
+// B operand is the point's gradient row written by the spatial kernel: no LDS, no atomics, no sorting inside
+// the loop, and a fixed summation order.  The four waves of a workgroup are summed through LDS, the
+// workgroups by hexplane_strip_reduce_kernel.  A point whose time rows differ from the run's (per-point
+// timestamps) takes the global-atomic path, so correctness does not depend on the shared timestamp.
+struct StripPlan {
+    int off[GS4D_MAX_LEVELS];     // float offset of the level's strip ([2][W][C]) in a workgroup's partial record
+    int points_per_wg;
+};
+
+#define TIME_BUCKETS 4      // 32-column buckets per pass: 8 accumulator tiles (128 registers)
+#define TIME_UNROLL 4       // MFMA k-steps (point pairs) whose loads are in flight together
+__global__ __launch_bounds__(256, 2) void hexplane_backward_time_kernel(
+    int P, int C, int L, PlaneTable T, StripPlan plan, const float* __restrict__ aabb,
+    const float* __restrict__ xyz, const float* __restrict__ tprime, const float* __restrict__ gtime,
+    float* __restrict__ strip_part, int* __restrict__ strip_rows, int strip_total)
+{
+    __shared__ float red[2 * 32 * TIME_BUCKETS * 32];    // [row][column of the pass][channel of the block]
+    __shared__ int s_row0[GS4D_MAX_LEVELS], s_row1[GS4D_MAX_LEVELS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int khalf = lane >> 5, col = lane & 31;
+    const int j = blockIdx.y;
+    const int itp = kTimeP[j];
+    const int axis = kPairA[itp];                       // the plane's spatial axis
+    const int pbeg = blockIdx.x * plan.points_per_wg, pend = min(P, pbeg + plan.points_per_wg);   // host: never empty
+    const int per_wave = ((pend - pbeg + 3) / 4 + 1) & ~1;                                      // even
+    const int wbeg = min(pend, pbeg + wave * per_wave), wend = min(pend, wbeg + per_wave);
+    const size_t slot = (size_t)blockIdx.x * 3 + j;
+    float* __restrict__ out = strip_part + slot * strip_total;
+
+    if (tid < L) {     // strip rows of this run: the time rows of its first point
+        const Corner c = corner_of(0.f, tprime[pbeg], T.w[tid * 6 + itp], T.h[tid * 6 + itp]);
+        s_row0[tid] = c.y0;
+        s_row1[tid] = c.y1;
+        strip_rows[(slot * GS4D_MAX_LEVELS + tid) * 2 + 0] = c.y0;
+        strip_rows[(slot * GS4D_MAX_LEVELS + tid) * 2 + 1] = c.y1;
+    }
+    __syncthreads();
+
+    const float lo = aabb[axis], hi = aabb[3 + axis];
+    for (int l = 0; l < L; l++) {
+        const int Wt = T.w[l * 6 + itp], Ht = T.h[l * 6 + itp];
+        const int row0 = s_row0[l], row1 = s_row1[l];
+        float* __restrict__ gplane = T.g[l * 6 + itp];
+        const int nbuckets = (Wt + 31) / 32;
+        for (int cb = 0; cb * 32 < C; cb++) {
+            const int ch = cb * 32 + col;
+            const bool chok = ch < C;
+            for (int b0 = 0; b0 < nbuckets; b0 += TIME_BUCKETS) {
+                f32x16 acc[2 * TIME_BUCKETS];
+#pragma unroll
+                for (int t = 0; t < 2 * TIME_BUCKETS; t++) acc[t] = (f32x16){0};
+                for (int p0 = wbeg; p0 < wend; p0 += 2 * TIME_UNROLL) {
+                    float u[TIME_UNROLL], tt[TIME_UNROLL], g[TIME_UNROLL];
+#pragma unroll
+                    for (int k = 0; k < TIME_UNROLL; k++) {
+                        const int p = min(p0 + 2 * k + khalf, pend - 1);
+                        u[k] = xyz[3 * (size_t)p + axis];
+                        tt[k] = tprime[p];
+                        g[k] = gtime[(((size_t)p * L + l) * 3 + j) * C + min(ch, C - 1)];
+                    }
+#pragma unroll
+                    for (int k = 0; k < TIME_UNROLL; k++) {
+                        const bool ok = p0 + 2 * k + khalf < wend;
+                        const Corner c = corner_of((u[k] - lo) * (2.0f / (hi - lo)) - 1.0f, tt[k], Wt, Ht);
+                        const bool in_strip = c.y0 == row0 && c.y1 == row1;
+                        float gk = (ok && chok) ? g[k] : 0.f;
+                        if (!in_strip) {                 // rare: per-point timestamps
+                            if (gk != 0.f && b0 == 0) {
+                                float* __restrict__ gb = gplane + ch;
+                                unsafeAtomicAdd(gb + (size_t)c.i00 * C, gk * c.w00);
+                                unsafeAtomicAdd(gb + (size_t)c.i01 * C, gk * c.w01);
+                                unsafeAtomicAdd(gb + (size_t)c.i10 * C, gk * c.w10);
+                                unsafeAtomicAdd(gb + (size_t)c.i11 * C, gk * c.w11);
+                            }
+                            gk = 0.f;
+                        }
+                        const bool merged = c.x1 == c.x0;   // right border: one texel (the weight of x1 is 0 there)
+#pragma unroll
+                        for (int bb = 0; bb < TIME_BUCKETS; bb++) {
+                            if (32 * (b0 + bb) >= Wt) break;          // narrower plane: fewer buckets (uniform)
+                            const int xg = 32 * (b0 + bb) + col;      // this lane's row of the A operand
+                            const bool m0 = c.x0 == xg, m1 = !merged && c.x1 == xg;
+                            const float a0 = (m0 ? (merged ? c.w00 + c.w01 : c.w00) : 0.f) + (m1 ? c.w01 : 0.f);
+                            const float a1 = (m0 ? (merged ? c.w10 + c.w11 : c.w10) : 0.f) + (m1 ? c.w11 : 0.f);
+                            acc[2 * bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, gk, acc[2 * bb], 0, 0, 0);
+                            acc[2 * bb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, gk, acc[2 * bb + 1], 0, 0, 0);
+                        }
+                    }
+                }
+                // sum the four waves in wave order through LDS
+                for (int w = 0; w < 4; w++) {
+                    if (wave == w) {
+#pragma unroll
+                        for (int t = 0; t < 2 * TIME_BUCKETS; t++) {
+#pragma unroll
+                            for (int q = 0; q < 16; q++) {
+                                const int xl = 32 * (t >> 1) + (q & 3) + 8 * (q >> 2) + 4 * khalf;   // column inside the pass
+                                float* dst = red + (((t & 1) * 32 * TIME_BUCKETS + xl) * 32 + col);
+                                if (w == 0) *dst = acc[t][q];
+                                else *dst += acc[t][q];
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                // this pass's columns of the workgroup's partial record
+                const int ncols = min(32 * TIME_BUCKETS, Wt - 32 * b0);
+                for (int i = tid; i < 2 * ncols * 32; i += 256) {
+                    const int c2 = i & 31, xl = (i >> 5) % ncols, r = (i >> 5) / ncols;
+                    if (cb * 32 + c2 < C)
+                        out[plan.off[l] + ((size_t)r * Wt + 32 * b0 + xl) * C + cb * 32 + c2] = red[((r * 32 * TIME_BUCKETS + xl) * 32) + c2];
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// Sums the workgroups' strips in workgroup order and adds each run of equal target rows to the plane
+// gradient (one atomic per element when every point shares the timestamp; the atomic only matters when
+// two strip rows of different runs alias the same texel row).
+__global__ __launch_bounds__(256) void hexplane_strip_reduce_kernel(int nwg, int C, int L, PlaneTable T, StripPlan plan,
+                                                                    const float* __restrict__ strip_part,
+                                                                    const int* __restrict__ strip_rows, int strip_total)
+{
+    const int j = blockIdx.y, itp = kTimeP[j];
+    const int e = blockIdx.x * 256 + threadIdx.x;       // element of the concatenated strips
+    if (e >= strip_total) return;
+    int l = -1;
+    for (int k = 0; k < L; k++)
+        if (plan.off[k] >= 0 && e >= plan.off[k] && e < plan.off[k] + 2 * T.w[k * 6 + itp] * C) l = k;
+    if (l < 0) return;
+    const int n = T.w[l * 6 + itp] * C;
+    const int r = (e - plan.off[l]) / n, i = (e - plan.off[l]) % n;
+    float* __restrict__ g = T.g[l * 6 + itp];
+    float acc = 0.f;
+    int cur = -1;
+    for (int w0 = 0; w0 < nwg; w0 += 8) {
+        int row[8]; float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {      // eight independent loads in flight
+            const size_t slot = (size_t)min(w0 + k, nwg - 1) * 3 + j;
+            row[k] = strip_rows[(slot * GS4D_MAX_LEVELS + l) * 2 + r];
+            v[k] = strip_part[slot * strip_total + e];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (w0 + k >= nwg) break;
+            if (row[k] != cur) {
+                if (cur >= 0 && acc != 0.f) unsafeAtomicAdd(g + (size_t)cur * n + i, acc);
+                acc = 0.f;
+                cur = row[k];
+            }
+            acc += v[k];
+        }
+    }
+    if (cur >= 0 && acc != 0.f) unsafeAtomicAdd(g + (size_t)cur * n + i, acc);
+}
+
+// dL_dpoints += (coordinate gradient through the planes) * d(normalised)/d(world); the t' part is
+// reduced per workgroup for the time/force embedding gradient (fixed order: deterministic given its inputs).
+__global__ __launch_bounds__(256) void hexplane_coord_reduce_kernel(int P, const float4* __restrict__ part,
+                                                                    const float* __restrict__ aabb,
+                                                                    const float* __restrict__ time,
+                                                                    const float* __restrict__ force, int use_time,
+                                                                    int use_force, float* __restrict__ dL_dpoints,
+                                                                    float* __restrict__ ft_partial)
+{
+    __shared__ float s[256][3];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (p < P) {
+        const float4 u = part[p];
+        const float d[3] = {u.x, u.y, u.z};
 #pragma unroll
         for (int a = 0; a < 3; a++) {
             const float lo = aabb[a], hi = aabb[3 + a];
-            dxyz[3 * (size_t)p + a] = dpts[a] * (2.0f / (hi - lo));
+            dL_dpoints[3 * (size_t)p + a] += d[a] * (2.0f / (hi - lo));
         }
-        dtprime[p] = dpts[3];
+        const float g = u.w;
+        a0 = g * (use_time ? time[p] : 0.f);
+        a1 = g * (use_force ? force[p] : 0.f);
+        a2 = g;
     }
+    s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 3; k++) s[threadIdx.x][k] += s[threadIdx.x + off][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) ft_partial[3 * (size_t)blockIdx.x + threadIdx.x] = s[0][threadIdx.x];
 }
 
 // ------------------------------------------------------------------ positional encodings
@@ -678,36 +896,39 @@ __global__ __launch_bounds__(256) void outputs_backward_kernel(OutArgs a, const 
     for (int k = 58; k < OUT_LD; k++) d[k] = 0.f;
 }
 
-// out[p] += a[p]  (3 floats per point)
-__global__ __launch_bounds__(256) void add3_kernel(size_t n, const float* __restrict__ a, float* __restrict__ out)
+// d(ft_w), d(ft_b) from the per-workgroup partial sums of hexplane_coord_reduce_kernel
+// (t' = w0*t + w1*f + b): single workgroup, fixed-order sum
+__global__ __launch_bounds__(256) void ft_embed_final_kernel(int nparts, const float* __restrict__ ft_partial,
+                                                             float* __restrict__ d_w, float* __restrict__ d_b)
 {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] += a[i];
-}
-
-// d(ft_w), d(ft_b) from dL/dt' (t' = w0*t + w1*f + b): single workgroup, fixed-order sum
-__global__ __launch_bounds__(1024) void ft_embed_backward_kernel(int P, const float* __restrict__ dtprime,
-                                                                 const float* __restrict__ time,
-                                                                 const float* __restrict__ force, int use_time,
-                                                                 int use_force, float* __restrict__ d_w,
-                                                                 float* __restrict__ d_b)
-{
-    __shared__ float s[1024][3];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int p = threadIdx.x; p < P; p += 1024) {
-        const float g = dtprime[p];
-        a0 += g * (use_time ? time[p] : 0.f);
-        a1 += g * (use_force ? force[p] : 0.f);
-        a2 += g;
-    }
-    s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2;
+    __shared__ float s[256][3];
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nparts; i += 256)
+        for (int k = 0; k < 3; k++) a[k] += ft_partial[3 * (size_t)i + k];
+    for (int k = 0; k < 3; k++) s[threadIdx.x][k] = a[k];
     __syncthreads();
-    for (int off = 512; off >= 1; off >>= 1) {
+    for (int off = 128; off >= 1; off >>= 1) {
         if ((int)threadIdx.x < off)
             for (int k = 0; k < 3; k++) s[threadIdx.x][k] += s[threadIdx.x + off][k];
         __syncthreads();
     }
     if (threadIdx.x == 0) { d_w[0] += s[0][0]; d_w[1] += s[0][1]; d_b[0] += s[0][2]; }
+}
+
+// per-workgroup partial record of the time-plane strips: [2][W][C] per level, widest time plane of the level
+static int strip_layout(const gs4d_deform_desc* d, int off[GS4D_MAX_LEVELS])
+{
+    int total = 0;
+    for (int lv = 0; lv < GS4D_MAX_LEVELS; lv++) {
+        off[lv] = -1;
+        if (lv >= d->L) continue;
+        int wmax = 0;
+        const int tp[3] = {2, 4, 5};
+        for (int j = 0; j < 3; j++) wmax = d->plane_w[lv * 6 + tp[j]] > wmax ? d->plane_w[lv * 6 + tp[j]] : wmax;
+        off[lv] = total;
+        total += 2 * wmax * d->C;
+    }
+    return total;
 }
 
 static int validate(const gs4d_deform_desc* d, int P)
@@ -764,8 +985,8 @@ size_t gs4d_deform_workspace_bytes(const gs4d_deform_desc* d, int P)
 }
 
 static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l, size_t P, float** dO, float** dH1,
-                          float** dZ, float** dT, float** dfeat, float** dxyz_hex, float** dtprime, float** slabs,
-                          size_t* slab_floats_per_job, size_t* bytes)
+                          float** dZ, float** dT, float** dfeat, float** dxyz_hex, float** dtprime, float** gtime,
+                          float** strip_part, int** strip_rows, float** slabs, size_t* slab_floats_per_job, size_t* bytes)
 {
     char* p = base;
     gs4d_obtain(p, *dO, P * OUT_LD);
@@ -773,8 +994,12 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     gs4d_obtain(p, *dZ, P * l.ldz);
     gs4d_obtain(p, *dT, P * WIDTH * 2);
     gs4d_obtain(p, *dfeat, P * l.F);
-    gs4d_obtain(p, *dxyz_hex, P * 3);
-    gs4d_obtain(p, *dtprime, P);
+    gs4d_obtain(p, *dxyz_hex, P * 4);                  // (dx,dy,dz,dt') per point, normalised coordinates
+    gs4d_obtain(p, *dtprime, 3 * ((P + 255) / 256) + 3);   // per-workgroup partial sums for the t' embedding
+    gs4d_obtain(p, *gtime, P * d->L * 3 * d->C);           // time-plane sample gradients, spatial -> strip kernel
+    int strip_off[GS4D_MAX_LEVELS];
+    gs4d_obtain(p, *strip_part, (size_t)STRIP_WGS * 3 * strip_layout(d, strip_off));
+    gs4d_obtain(p, *strip_rows, (size_t)STRIP_WGS * 3 * GS4D_MAX_LEVELS * 2);
     const size_t nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
     int kmax = l.F > l.head_in[0] ? l.F : l.head_in[0];
     for (int h = 0; h < NHEAD; h++) kmax = l.head_in[h] > kmax ? l.head_in[h] : kmax;
@@ -788,9 +1013,10 @@ size_t gs4d_deform_backward_scratch_bytes(const gs4d_deform_desc* d, int P)
 {
     if (validate(d, P)) return 0;
     const Layout l = make_layout(d);
-    float *a, *b, *c, *e, *f, *g, *h, *s;
+    float *a, *b, *c, *e, *f, *g, *h, *gt, *sp, *s;
+    int* sr;
     size_t per = 0, bytes = 0;
-    carve_scratch(nullptr, d, l, (size_t)P, &a, &b, &c, &e, &f, &g, &h, &s, &per, &bytes);
+    carve_scratch(nullptr, d, l, (size_t)P, &a, &b, &c, &e, &f, &g, &h, &gt, &sp, &sr, &s, &per, &bytes);
     return bytes;
 }
 
@@ -899,10 +1125,11 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
     }
     const Layout l = make_layout(d);
     Workspace w = carve_workspace(workspace, d, l, (size_t)P, nullptr);
-    float *dO, *dH1, *dZ, *dT, *dfeat, *dxyz_hex, *dtprime, *slabs;
+    float *dO, *dH1, *dZ, *dT, *dfeat, *dxyz_hex, *dtprime, *gtime, *strip_part, *slabs;
+    int* strip_rows;
     size_t slab_per_job = 0;
-    carve_scratch(scratch, d, l, (size_t)P, &dO, &dH1, &dZ, &dT, &dfeat, &dxyz_hex, &dtprime, &slabs, &slab_per_job,
-                  nullptr);
+    carve_scratch(scratch, d, l, (size_t)P, &dO, &dH1, &dZ, &dT, &dfeat, &dxyz_hex, &dtprime, &gtime, &strip_part,
+                  &strip_rows, &slabs, &slab_per_job, nullptr);
     const int nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
 
     Gs4dProfScope* mlp_scope = new Gs4dProfScope("mlp_backward", s);
@@ -1034,14 +1261,25 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         }
         int lanes_shift = 0;
         while ((1 << lanes_shift) < (d->C < 64 ? d->C : 64)) lanes_shift++;
+        StripPlan plan;
+        const int strip_floats = strip_layout(d, plan.off);
+        int ppw = (P + STRIP_WGS - 1) / STRIP_WGS;
+        plan.points_per_wg = ppw;
+        const int nwg = (P + ppw - 1) / ppw;
         const size_t threads = (size_t)P << lanes_shift;
-        hipLaunchKernelGGL(hexplane_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, d->C,
-                           d->L, lanes_shift, T, d->aabb, points, w.tprime, dfeat, l.F, dxyz_hex, dtprime);
+        hipLaunchKernelGGL(hexplane_backward_spatial_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P,
+                           d->C, d->L, lanes_shift, T, d->aabb, points, w.tprime, dfeat, l.F, (float4*)dxyz_hex, gtime);
+        hipLaunchKernelGGL(hexplane_backward_time_kernel, dim3(nwg, 3), dim3(256), 0, s,
+                           P, d->C, d->L, T, plan, d->aabb, points, w.tprime, gtime, strip_part, strip_rows,
+                           strip_floats);
+        if (strip_floats > 0)
+            hipLaunchKernelGGL(hexplane_strip_reduce_kernel, dim3((strip_floats + 255) / 256, 3), dim3(256), 0, s, nwg, d->C,
+                               d->L, T, plan, strip_part, strip_rows, strip_floats);
         GS4D_LAUNCH_CHECK("hexplane_backward", 0, s);
-        hipLaunchKernelGGL(add3_kernel, dim3((unsigned)(((size_t)P * 3 + 255) / 256)), dim3(256), 0, s, (size_t)P * 3,
-                           dxyz_hex, dL_dpoints);
-        hipLaunchKernelGGL(ft_embed_backward_kernel, dim3(1), dim3(1024), 0, s, P, dtprime, time, force, d->use_time,
-                           d->use_force, g->ft_w, g->ft_b);
+        const int nred = (P + 255) / 256;
+        hipLaunchKernelGGL(hexplane_coord_reduce_kernel, dim3(nred), dim3(256), 0, s, P, (const float4*)dxyz_hex, d->aabb,
+                           time, force, d->use_time, d->use_force, dL_dpoints, dtprime);
+        hipLaunchKernelGGL(ft_embed_final_kernel, dim3(1), dim3(256), 0, s, nred, dtprime, g->ft_w, g->ft_b);
         GS4D_LAUNCH_CHECK("deform_tail_backward", 0, s);
     }
     return GS4D_OK;

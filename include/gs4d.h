@@ -50,9 +50,12 @@ int gs4d_abi_version(void);
  * stream it is launched on; gs4d_profile_read() waits for the recorded events and returns the
  * accumulated milliseconds and launch count of one stage ("preprocess", "scan", "emit_keys",
  * "radix_sort", "tile_ranges", "blend_forward", "blend_backward", "geom_backward",
- * "hexplane_forward", "hexplane_backward", "mlp_forward", "mlp_backward", "knn").
+ * "hexplane_forward", "hexplane_backward", "mlp_forward", "mlp_backward", "knn", ...).
+ * Every recorded event costs device idle time (a barrier packet each), so a throughput run should
+ * time ONE stage: gs4d_profile_select("stage") restricts recording to it, NULL or "" selects all.
  */
 void gs4d_profile_enable(int on);
+void gs4d_profile_select(const char* stage);
 void gs4d_profile_reset(void);
 int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
 
