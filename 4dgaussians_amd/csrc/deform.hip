@@ -29,8 +29,13 @@
 
 #define WIDTH 64            // net_width of every supported config
 #define NHEAD 4             // pos, scales, rotations, shs
-#define OUT_LD 64           // row pitch of the heads' raw output matrix O
+#define OUT_LD 72           // row pitch of the heads' raw output matrix O: every head's columns start on a multiple of 8
+#define OC_X 0              //   pos 0..2 | scales 8..10 | rotations 16..19 | shs 24..71   (the gaps are zero in dO)
+#define OC_S 8
+#define OC_R 16
+#define OC_SH 24
 #define ROWS_PER_WG 128
+#define GEMM_TARGET_WGS 1024
 #define DW_ROWS_PER_WG 512
 #define STRIP_WGS 256           // point runs of the time-plane strip kernel (x3 planes)
 
@@ -53,25 +58,25 @@ static Layout make_layout(const gs4d_deform_desc* d)
 {
     Layout l;
     l.F = d->L * d->C;
+    // every segment owns a multiple of 8 columns (zero padding) so the GEMM can fetch float4 K blocks
     l.oX = WIDTH;
-    l.oS = l.oX + 6 * d->pos_pe;
-    l.oR = l.oS + 6 * d->sr_pe;
-    l.oT = l.oR + 8 * d->sr_pe;
+    l.oS = l.oX + (6 * d->pos_pe + 7) / 8 * 8;
+    l.oR = l.oS + (6 * d->sr_pe + 7) / 8 * 8;
+    l.oT = l.oR + (8 * d->sr_pe + 7) / 8 * 8;
     l.oF = l.oT + 1 + 2 * d->time_pe;
     l.Kz = l.oF + 1 + 2 * d->force_pe;
-    l.ldz = (l.Kz + 3) / 4 * 4;
+    l.ldz = (l.Kz + 7) / 8 * 8;
     l.e = l.Kz - l.oT;
     const int seg[NHEAD] = {l.oX, l.oS, l.oR, -1};
     const int seglen[NHEAD] = {6 * d->pos_pe, 6 * d->sr_pe, 8 * d->sr_pe, 0};
     const int outs[NHEAD] = {3, 3, 4, 48};
-    int oc = 0;
+    const int ocol[NHEAD] = {OC_X, OC_S, OC_R, OC_SH};
     for (int h = 0; h < NHEAD; h++) {
         l.head_seg[h] = seg[h];
         l.head_seglen[h] = seglen[h];
         l.head_in[h] = WIDTH + seglen[h] + l.e;
         l.head_out[h] = outs[h];
-        l.head_ocol[h] = oc;
-        oc += outs[h];
+        l.head_ocol[h] = ocol[h];
     }
     return l;
 }
@@ -490,22 +495,28 @@ __global__ __launch_bounds__(256) void pe_forward_kernel(PeArgs a, const float* 
                                                          const float* __restrict__ rots, const float* __restrict__ time,
                                                          const float* __restrict__ force, float* __restrict__ Z)
 {
-    const int ncol = a.Kz - a.oX;
+    const int ncol = a.ldz - a.oX;                  // includes the zero padding of every segment
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const size_t p = gid / ncol;
     if (p >= (size_t)a.P) return;
     const int col = a.oX + (int)(gid % ncol);
     float out;
-    if (col < a.oT) {
+    if (col >= a.Kz) {
+        out = 0.f;
+    } else if (col < a.oT) {
         const float* src; int dim, npe, c0;
         if (col < a.oS) { src = xyz + 3 * p; dim = 3; npe = a.pos_pe; c0 = a.oX; }
         else if (col < a.oR) { src = scales + 3 * p; dim = 3; npe = a.sr_pe; c0 = a.oS; }
         else { src = rots + 4 * p; dim = 4; npe = a.sr_pe; c0 = a.oR; }
         int k = col - c0;
-        const bool is_cos = k >= dim * npe;
-        if (is_cos) k -= dim * npe;
-        const float arg = src[k / npe] * (float)(1 << (k % npe));
-        out = is_cos ? cosf(arg) : sinf(arg);
+        if (k >= 2 * dim * npe) {
+            out = 0.f;                               // segment padding
+        } else {
+            const bool is_cos = k >= dim * npe;
+            if (is_cos) k -= dim * npe;
+            const float arg = src[k / npe] * (float)(1 << (k % npe));
+            out = is_cos ? cosf(arg) : sinf(arg);
+        }
     } else {
         const bool is_force = col >= a.oF;
         const float x = is_force ? force[p] : time[p];
@@ -547,7 +558,12 @@ __global__ __launch_bounds__(256) void pe_backward_kernel(PeArgs a, const float*
 }
 
 // ------------------------------------------------------------------ MFMA row-block GEMM
-// Y[rows, ycol0 + j] (op)= mask( sum_k actA(A[rows, acol(k)]) * B[k][j] + bias[j] ), j < N <= 64.
+// Y[rows, ycol0 + j] = mask( sum_k actA(A[rows, acol(k)]) * B[k][j] + bias[j] ), j < N <= 64.
+//
+// A's K columns are up to three segments of the source row.  Every segment starts on a 4-float boundary and
+// owns pad8(len) columns of the row (the layouts in this file pad with zeros), so a lane can fetch its
+// operand as one float4 per 8-wide K block.  B rows follow the TRUE column order (no padding); the staged
+// copy in LDS has zero rows where A has padding.
 struct GemmJob {
     const float* A; int lda;
     int a_nseg; int a_beg[3]; int a_len[3];        // source columns of A, concatenated; K = sum(a_len)
@@ -561,137 +577,129 @@ struct GemmJob {
 };
 struct GemmJobs { GemmJob j[8]; };
 
-#define KCH 32        // K chunk staged per step
-#define SB_PITCH 65   // row pitch of the staged B operand: conflict-free for both the transposing store and the fragment read
-// Pipeline per 32-wide K chunk: the next chunk's 128x32 A tile is fetched into registers (16 independent
-// coalesced loads per lane, all issued before the MFMAs), the MFMAs run on the current LDS buffer, then the
-// registers are written to the other LDS buffer; one barrier per chunk.
+static inline __host__ __device__ int pad8(int v) { return (v + 7) & ~7; }
+static inline __host__ __device__ int gemm_kp(const GemmJob& J)
+{
+    int kp = 0;
+    for (int s = 0; s < J.a_nseg; s++) kp += pad8(J.a_len[s]);
+    return kp;
+}
+
+#define SB_PITCH 65   // row pitch of the staged B operand: conflict-free for the transposing store and the fragment read
+#define GEMM_GB 8     // 8-wide K blocks per register group (one group is in flight while the previous one feeds the MFMAs)
+#define GEMM_MAX_KB 40
+
+// Design: the workgroup stages B (<= 320 x 64) in LDS once and then walks row blocks of 128 (persistent grid);
+// each wave owns 32 rows and streams its A operand straight from global memory into registers: with
+// v_mfma_f32_32x32x2_f32 lane (i, h) supplies A[i][k] for one k per instruction, and since the sum over k
+// may run in any order as long as A and B agree, lane (i, h) takes k = 8m + 4h + s (s = 0..3) of block m --
+// one 16-byte load per block -- while B is read from LDS row 8m + 4h + s.  No LDS round trip and no
+// barrier in the main loop; the next group of blocks (or the next row block) is loaded while the current
+// one is multiplied.
 __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 {
     extern __shared__ float smem[];
+    __shared__ int s_acol[GEMM_MAX_KB];
     const GemmJob& J = jobs.j[blockIdx.y];
-    const int Kpad = (J.K + KCH - 1) / KCH * KCH;
-    float* sB = smem;                                   // [Kpad][SB_PITCH]
-    float* sA = smem + (size_t)Kpad * SB_PITCH;         // 2 x [128][33]
+    const int Kp = gemm_kp(J);
+    const int Kb = Kp >> 3;
+    float* sB = smem;                                   // [Kp][SB_PITCH]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS_PER_WG;
 
-    // stage B, reading along the source's contiguous axis; loads are unconditional (clamped address,
-    // value selected afterwards) and issued eight at a time so their latencies overlap
-    if (J.b_transposed) {
-        for (int k = tid & 31; k < Kpad; k += 32) {
-            int kl = min(k, J.K - 1), sg = 0;
-            while (sg < J.b_nseg - 1 && kl >= J.b_rows[sg]) { kl -= J.b_rows[sg]; sg++; }
-            const float* src = J.B[sg] + (size_t)J.b_col0[sg] * J.b_ld[sg] + kl;
-            const int ld = J.b_ld[sg];
-            float v[8];
+    // ---- stage B (zero rows for A's padding columns) and the A column of every K block
+    for (int kp = tid & 31; kp < Kp; kp += 32) {
+        // padded k -> (segment, local k) -> true k
+        int sg = 0, kl = kp, ktrue = 0;
+        while (sg < J.a_nseg - 1 && kl >= pad8(J.a_len[sg])) { kl -= pad8(J.a_len[sg]); ktrue += J.a_len[sg]; sg++; }
+        const bool kvalid = kl < J.a_len[sg];
+        ktrue += min(kl, J.a_len[sg] - 1);
+        if ((kp & 7) == 0 && tid < 32 * 8) { if ((tid >> 5) == 0) s_acol[kp >> 3] = J.a_beg[sg] + kl; }
+        int bs = 0, bl = ktrue;
+        while (bs < J.b_nseg - 1 && bl >= J.b_rows[bs]) { bl -= J.b_rows[bs]; bs++; }
+        const float* src = J.B[bs];
+        const int ld = J.b_ld[bs], c0 = J.b_col0[bs];
+        float v[8];
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const int j = (tid >> 5) + 8 * jj;
-                v[jj] = src[(size_t)min(j, J.N - 1) * ld];
-            }
-#pragma unroll
-            for (int jj = 0; jj < 8; jj++) {
-                const int j = (tid >> 5) + 8 * jj;
-                sB[k * SB_PITCH + j] = (k < J.K && j < J.N) ? v[jj] : 0.f;
-            }
+        for (int jj = 0; jj < 8; jj++) {                // eight independent loads in flight
+            const int j = min((tid >> 5) + 8 * jj, J.N - 1);
+            v[jj] = J.b_transposed ? src[(size_t)(c0 + j) * ld + bl] : src[(size_t)bl * ld + c0 + j];
         }
-    } else {
-        const int j = tid & 63;
-        const int jc = min(j, J.N - 1);
-        for (int kb = tid >> 6; kb < Kpad; kb += 32) {
-            float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = kb + 4 * u;
-                int kl = min(k, J.K - 1), sg = 0;
-                while (sg < J.b_nseg - 1 && kl >= J.b_rows[sg]) { kl -= J.b_rows[sg]; sg++; }
-                v[u] = J.B[sg][(size_t)kl * J.b_ld[sg] + J.b_col0[sg] + jc];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int k = kb + 4 * u;
-                if (k < Kpad) sB[k * SB_PITCH + j] = (k < J.K && j < J.N) ? v[u] : 0.f;
-            }
+        for (int jj = 0; jj < 8; jj++) {
+            const int j = (tid >> 5) + 8 * jj;
+            sB[kp * SB_PITCH + j] = (kvalid && j < J.N) ? v[jj] : 0.f;
         }
     }
+    __syncthreads();
 
-    const int kk_l = tid & 31, r_l = tid >> 5;          // this lane stages column kk_l of rows r_l + 8n
-    float nxt[16];
-    int nxt_k = 0;
-    auto fetch = [&](int k0) {
-        const int k = k0 + kk_l;
-        int kl = min(k, J.K - 1), sg = 0;
-        while (sg < J.a_nseg - 1 && kl >= J.a_len[sg]) { kl -= J.a_len[sg]; sg++; }
-        // unconditional loads from clamped addresses (out-of-range rows / columns are zeroed in stash()):
-        // no branches and no ALU use of the loaded values before the MFMAs
-        const float* src = J.A + J.a_beg[sg] + kl;
+    const int i = lane & 31, khalf = lane >> 5;
+    const bool two = J.N > 32;
+    const int nrb = (P + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int NG = (Kb + GEMM_GB - 1) / GEMM_GB;
+    const int my_rb = nrb > (int)blockIdx.x ? (nrb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int T = my_rb * NG;                           // flattened (row block, group) steps of this workgroup
+
+    auto load_group = [&](int t, float4 (&dst)[GEMM_GB]) {
+        const int rb = blockIdx.x + (t / NG) * gridDim.x, g = t % NG;
+        const int row = min(rb * ROWS_PER_WG + wave * 32 + i, P - 1);
+        const float* arow = J.A + (size_t)row * J.lda + 4 * khalf;
 #pragma unroll
-        for (int n = 0; n < 16; n++) {
-            const int row = min(row0 + r_l + 8 * n, P - 1);
-            nxt[n] = src[(size_t)row * J.lda];
-        }
-        nxt_k = k;
-    };
-    auto stash = [&](float* buf) {
-#pragma unroll
-        for (int n = 0; n < 16; n++) {
-            float v = (nxt_k < J.K && row0 + r_l + 8 * n < P) ? nxt[n] : 0.f;
-            if (J.relu_a) v = fmaxf(v, 0.f);
-            buf[(r_l + 8 * n) * 33 + kk_l] = v;
+        for (int b = 0; b < GEMM_GB; b++) {
+            const int m = min(g * GEMM_GB + b, Kb - 1);  // clamped: the surplus blocks of the last group are never multiplied
+            dst[b] = *reinterpret_cast<const float4*>(arow + s_acol[m]);
         }
     };
 
     f32x16 acc0 = {0}, acc1 = {0};
-    const bool two = J.N > 32;
-    const int arow = wave * 32 + (lane & 31);
-    const int khalf = lane >> 5;
-    const int nchunks = Kpad / KCH;
-    fetch(0);
-    stash(sA);
-    __syncthreads();
-    for (int c = 0; c < nchunks; c++) {
-        const float* cur = sA + (c & 1) * (ROWS_PER_WG * 33);
-        if (c + 1 < nchunks) fetch((c + 1) * KCH);
-        const float* bcur = sB + (size_t)(c * KCH + khalf) * SB_PITCH + (lane & 31);
-        if (two) {
-#pragma unroll
-            for (int kk = 0; kk < KCH; kk += 2) {
-                const float a = cur[arow * 33 + kk + khalf];
-                const float b0 = bcur[kk * SB_PITCH];
-                const float b1 = bcur[kk * SB_PITCH + 32];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int kk = 0; kk < KCH; kk += 2) {
-                const float a = cur[arow * 33 + kk + khalf];
-                const float b0 = bcur[kk * SB_PITCH];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
-            }
-        }
-        if (c + 1 < nchunks) stash(sA + ((c + 1) & 1) * (ROWS_PER_WG * 33));
-        __syncthreads();
-    }
-    // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
     const int col = lane & 31;
     const float bias0 = (J.bias && col < J.N) ? J.bias[col] : 0.f;
     const float bias1 = (J.bias && col + 32 < J.N) ? J.bias[col + 32] : 0.f;
+
+    auto compute_group = [&](int t, const float4 (&src)[GEMM_GB]) {
+        const int rb = blockIdx.x + (t / NG) * gridDim.x, g = t % NG;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int row = row0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (row >= P) continue;
-        if (col < J.N) {
-            float v = acc0[r] + bias0;
-            if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col] > 0.f)) v = 0.f;
-            J.Y[(size_t)row * J.ldy + J.ycol0 + col] = v;
+        for (int b = 0; b < GEMM_GB; b++) {
+            const int m = g * GEMM_GB + b;
+            if (m >= Kb) break;
+            const float av[4] = {src[b].x, src[b].y, src[b].z, src[b].w};
+            const float* brow = sB + (size_t)(8 * m + 4 * khalf) * SB_PITCH + col;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float a = J.relu_a ? fmaxf(av[q], 0.f) : av[q];
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[q * SB_PITCH], acc0, 0, 0, 0);
+                if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[q * SB_PITCH + 32], acc1, 0, 0, 0);
+            }
         }
-        if (two && col + 32 < J.N) {
-            float v = acc1[r] + bias1;
-            if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col + 32] > 0.f)) v = 0.f;
-            J.Y[(size_t)row * J.ldy + J.ycol0 + col + 32] = v;
+        if (g == NG - 1) {
+            // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
+            const int row0 = rb * ROWS_PER_WG + wave * 32;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (row >= P) continue;
+                if (col < J.N) {
+                    float v = acc0[r] + bias0;
+                    if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col] > 0.f)) v = 0.f;
+                    J.Y[(size_t)row * J.ldy + J.ycol0 + col] = v;
+                }
+                if (two && col + 32 < J.N) {
+                    float v = acc1[r] + bias1;
+                    if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col + 32] > 0.f)) v = 0.f;
+                    J.Y[(size_t)row * J.ldy + J.ycol0 + col + 32] = v;
+                }
+            }
+            acc0 = (f32x16){0};
+            acc1 = (f32x16){0};
         }
+    };
+
+    float4 buf0[GEMM_GB], buf1[GEMM_GB];
+    if (T > 0) load_group(0, buf0);
+    for (int t = 0; t < T; t += 2) {
+        if (t + 1 < T) load_group(t + 1, buf1);
+        compute_group(t, buf0);
+        if (t + 2 < T) load_group(t + 2, buf0);
+        if (t + 1 < T) compute_group(t + 1, buf1);
     }
 }
 
@@ -804,13 +812,13 @@ __global__ __launch_bounds__(256) void outputs_forward_kernel(OutArgs a, const f
     if (p >= (size_t)a.P) return;
     const int c = (int)(gid % 58);
     const float* o = O + p * OUT_LD;
-    if (c < 3) o_xyz[3 * p + c] = a.no_dx ? xyz[3 * p + c] : xyz[3 * p + c] + o[c];
-    else if (c < 6) o_scales[3 * p + c - 3] = a.no_ds ? scales[3 * p + c - 3] : scales[3 * p + c - 3] + o[c];
+    if (c < 3) o_xyz[3 * p + c] = a.no_dx ? xyz[3 * p + c] : xyz[3 * p + c] + o[OC_X + c];
+    else if (c < 6) o_scales[3 * p + c - 3] = a.no_ds ? scales[3 * p + c - 3] : scales[3 * p + c - 3] + o[OC_S + c - 3];
     else if (c < 10) {
         const int k = c - 6;
         const float4 q1 = reinterpret_cast<const float4*>(rots)[p];
         if (a.no_dr) { o_rots[4 * p + k] = (&q1.x)[k]; return; }
-        const float4 q2 = make_float4(o[6], o[7], o[8], o[9]);
+        const float4 q2 = make_float4(o[OC_R], o[OC_R + 1], o[OC_R + 2], o[OC_R + 3]);
         if (!a.apply_rotation) { o_rots[4 * p + k] = (&q1.x)[k] + (&q2.x)[k]; return; }
         float q[4];
         q[0] = q1.x * q2.x - q1.y * q2.y - q1.z * q2.z - q1.w * q2.w;
@@ -821,7 +829,7 @@ __global__ __launch_bounds__(256) void outputs_forward_kernel(OutArgs a, const f
         o_rots[4 * p + k] = q[k] / nrm;
     } else {
         const int k = c - 10;
-        o_shs[48 * p + k] = a.no_dshs ? shs[48 * p + k] : shs[48 * p + k] + o[c];
+        o_shs[48 * p + k] = a.no_dshs ? shs[48 * p + k] : shs[48 * p + k] + o[OC_SH + k];
     }
 }
 
@@ -843,13 +851,13 @@ __global__ __launch_bounds__(256) void outputs_backward_kernel(OutArgs a, const 
     for (int c = 0; c < 3; c++) {
         const float g = g_xyz[3 * p + c];
         dxyz[3 * p + c] = g;
-        d[c] = a.no_dx ? 0.f : g;
+        d[OC_X + c] = a.no_dx ? 0.f : g;
     }
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         const float g = g_scales[3 * p + c];
         dscales[3 * p + c] = g;
-        d[3 + c] = a.no_ds ? 0.f : g;
+        d[OC_S + c] = a.no_ds ? 0.f : g;
     }
     const float4 gq = reinterpret_cast<const float4*>(g_rots)[p];
     float dq1[4], dq2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -859,7 +867,7 @@ __global__ __launch_bounds__(256) void outputs_backward_kernel(OutArgs a, const 
         dq1[0] = dq2[0] = gq.x; dq1[1] = dq2[1] = gq.y; dq1[2] = dq2[2] = gq.z; dq1[3] = dq2[3] = gq.w;
     } else {
         const float4 q1 = reinterpret_cast<const float4*>(rots)[p];
-        const float4 q2 = make_float4(o[6], o[7], o[8], o[9]);
+        const float4 q2 = make_float4(o[OC_R], o[OC_R + 1], o[OC_R + 2], o[OC_R + 3]);
         float q[4];
         q[0] = q1.x * q2.x - q1.y * q2.y - q1.z * q2.z - q1.w * q2.w;
         q[1] = q1.x * q2.y + q1.y * q2.x + q1.z * q2.w - q1.w * q2.z;
@@ -885,15 +893,17 @@ __global__ __launch_bounds__(256) void outputs_backward_kernel(OutArgs a, const 
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         drots[4 * p + k] = dq1[k];
-        d[6 + k] = dq2[k];
+        d[OC_R + k] = dq2[k];
     }
     for (int k = 0; k < 48; k++) {
         const float g = g_shs[48 * p + k];
         dshs[48 * p + k] = g;
-        d[10 + k] = a.no_dshs ? 0.f : g;
+        d[OC_SH + k] = a.no_dshs ? 0.f : g;
     }
 #pragma unroll
-    for (int k = 58; k < OUT_LD; k++) d[k] = 0.f;
+    for (int k = 3; k < 8; k++) { d[OC_X + k] = 0.f; d[OC_S + k] = 0.f; }
+#pragma unroll
+    for (int k = 4; k < 8; k++) d[OC_R + k] = 0.f;
 }
 
 // d(ft_w), d(ft_b) from the per-workgroup partial sums of hexplane_coord_reduce_kernel
@@ -935,6 +945,7 @@ static int validate(const gs4d_deform_desc* d, int P)
 {
     if (!d || P < 0) { gs4d_set_error("deform: null descriptor or negative P"); return GS4D_EINVAL; }
     if (d->C < 4 || d->C > 256 || (d->C & (d->C - 1))) { gs4d_set_error("deform: plane channels must be a power of two in [4,256], got %d", d->C); return GS4D_EINVAL; }
+    if ((d->L * d->C) % 8) { gs4d_set_error("deform: levels * channels must be a multiple of 8, got %d", d->L * d->C); return GS4D_EINVAL; }
     if (d->L < 1 || d->L > GS4D_MAX_LEVELS) { gs4d_set_error("deform: levels must be 1..%d", GS4D_MAX_LEVELS); return GS4D_EINVAL; }
     if (d->trunk_layers < 1 || d->trunk_layers > GS4D_MAX_TRUNK) { gs4d_set_error("deform: trunk_layers must be 1..%d", GS4D_MAX_TRUNK); return GS4D_EINVAL; }
     if (d->pos_pe < 0 || d->pos_pe > 10 || d->sr_pe < 0 || d->sr_pe > 8 || d->time_pe < 0 || d->time_pe > 15 || d->force_pe < 0 || d->force_pe > 15) {
@@ -944,19 +955,28 @@ static int validate(const gs4d_deform_desc* d, int P)
     return GS4D_OK;
 }
 
-static size_t gemm_lds_bytes(int K) { return ((size_t)((K + KCH - 1) / KCH * KCH) * SB_PITCH + (size_t)2 * ROWS_PER_WG * 33) * sizeof(float); }
+static size_t gemm_lds_bytes(int Kp) { return (size_t)Kp * SB_PITCH * sizeof(float); }
 
 static int launch_gemm(int P, GemmJobs& jobs, int njobs, hipStream_t s)
 {
-    int Kmax = 0;
-    for (int i = 0; i < njobs; i++) Kmax = jobs.j[i].K > Kmax ? jobs.j[i].K : Kmax;
-    const size_t lds = gemm_lds_bytes(Kmax);
+    int Kpmax = 0;
+    for (int i = 0; i < njobs; i++) {
+        const GemmJob& j = jobs.j[i];
+        const int kp = gemm_kp(j);
+        Kpmax = kp > Kpmax ? kp : Kpmax;
+        bool ok = ((uintptr_t)j.A & 15) == 0 && (j.lda & 3) == 0 && kp <= 8 * GEMM_MAX_KB && j.N >= 1 && j.N <= 64;
+        for (int sg = 0; sg < j.a_nseg; sg++) ok = ok && (j.a_beg[sg] & 3) == 0 && j.a_beg[sg] + pad8(j.a_len[sg]) <= j.lda;
+        if (!ok) { gs4d_set_error("deform gemm: operand %d violates the 16-byte / pad-8 layout rules", i); return GS4D_EINVAL; }
+    }
+    const size_t lds = gemm_lds_bytes(Kpmax);
     static bool attr_set = false;
     if (!attr_set) {
-        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_rows_kernel, dim3((P + ROWS_PER_WG - 1) / ROWS_PER_WG, njobs), dim3(256), lds, s, P, jobs);
+    const int nrb = (P + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int per_job = (GEMM_TARGET_WGS + njobs - 1) / njobs;       // persistent: ~4 workgroups per CU in total
+    hipLaunchKernelGGL(gemm_rows_kernel, dim3(nrb < per_job ? nrb : per_job, njobs), dim3(256), lds, s, P, jobs);
     GS4D_LAUNCH_CHECK("deform_gemm", 0, s);
     return GS4D_OK;
 }
@@ -1056,7 +1076,7 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
     PeArgs pa = {P, l.ldz, l.oX, l.oS, l.oR, l.oT, l.oF, l.Kz, d->pos_pe, d->sr_pe, d->time_pe, d->force_pe,
                  d->use_time, d->use_force};
     {
-        const size_t threads = (size_t)P * (l.Kz - l.oX);
+        const size_t threads = (size_t)P * (l.ldz - l.oX);
         hipLaunchKernelGGL(pe_forward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pa, points,
                            scales, rotations, time, force, w.Z);
         GS4D_LAUNCH_CHECK("pe_forward", 0, s);

@@ -119,8 +119,20 @@ def _linear(sd, name, x):
     return x @ sd[name + ".weight"].T + sd[name + ".bias"]
 
 
-def _head(sd, name, x):
-    return _linear(sd, name + ".3", torch.relu(_linear(sd, name + ".1", torch.relu(x))))
+def _note_relu(cap, x):
+    """Track, per point, how close any ReLU input comes to zero: an input within float32 rounding of 0 is
+    a discrete decision that two correct float32 implementations may take differently (test masks)."""
+    if cap is not None:
+        a = x.detach().abs()
+        m = torch.where(a == 0, torch.full_like(a, float("inf")), a).min(dim=1).values   # exact zeros are exact everywhere
+        cap["relu_margin"] = m if "relu_margin" not in cap else torch.minimum(cap["relu_margin"], m)
+
+
+def _head(sd, name, x, cap=None):
+    _note_relu(cap, x)
+    h1 = _linear(sd, name + ".1", torch.relu(x))
+    _note_relu(cap, h1)
+    return _linear(sd, name + ".3", torch.relu(h1))
 
 
 def quat_mul_normalized(q1, q2):
@@ -133,8 +145,9 @@ def quat_mul_normalized(q1, q2):
 
 
 def forward_dynamic(sd: Dict[str, torch.Tensor], cfg: DeformConfig, points, scales, rotations, opacity, shs, time,
-                    force):
-    """deform_network.forward_dynamic with prev_frames=None -> (means3D, scales, rotations, opacity, shs)."""
+                    force, capture=None):
+    """deform_network.forward_dynamic with prev_frames=None -> (means3D, scales, rotations, opacity, shs).
+    capture: optional dict that receives "relu_margin" [P] (see _note_relu)."""
     if not cfg.blend_time_force:
         raise NotImplementedError("only blend_time_force=True runs in the reference (SURVEY.md fact 3)")
     D = "deformation_net."
@@ -151,14 +164,15 @@ def forward_dynamic(sd: Dict[str, torch.Tensor], cfg: DeformConfig, points, scal
     feat = hexplane_features(sd, cfg, point_emb[:, :3], tprime)
     h = _linear(sd, D + "feature_out2.0", feat)
     for i in range(max(cfg.defor_depth - 1, 0)):
+        _note_relu(capture, h)
         h = _linear(sd, D + f"feature_out2.{2 * i + 2}", torch.relu(h))
-    pts = points if cfg.no_dx else points + _head(sd, D + "pos_deform", torch.cat((h, point_emb[:, 3:], time_emb, force_emb), 1))
-    sc = scales if cfg.no_ds else scales + _head(sd, D + "scales_deform", torch.cat((h, scales_emb[:, 3:], time_emb, force_emb), 1))
+    pts = points if cfg.no_dx else points + _head(sd, D + "pos_deform", torch.cat((h, point_emb[:, 3:], time_emb, force_emb), 1), capture)
+    sc = scales if cfg.no_ds else scales + _head(sd, D + "scales_deform", torch.cat((h, scales_emb[:, 3:], time_emb, force_emb), 1), capture)
     if cfg.no_dr:
         rot = rotations
     else:
-        dr = _head(sd, D + "rotations_deform", torch.cat((h, rot_emb[:, 4:], time_emb, force_emb), 1))
+        dr = _head(sd, D + "rotations_deform", torch.cat((h, rot_emb[:, 4:], time_emb, force_emb), 1), capture)
         rot = quat_mul_normalized(rotations, dr) if cfg.apply_rotation else rotations + dr
-    op = opacity if cfg.no_do else opacity + _head(sd, D + "opacity_deform", torch.cat((h, time_emb, force_emb), 1))
-    sh = shs if cfg.no_dshs else shs + _head(sd, D + "shs_deform", torch.cat((h, time_emb, force_emb), 1)).reshape(shs.shape[0], 16, 3)
+    op = opacity if cfg.no_do else opacity + _head(sd, D + "opacity_deform", torch.cat((h, time_emb, force_emb), 1), capture)
+    sh = shs if cfg.no_dshs else shs + _head(sd, D + "shs_deform", torch.cat((h, time_emb, force_emb), 1), capture).reshape(shs.shape[0], 16, 3)
     return pts, sc, rot, op, sh

@@ -84,6 +84,18 @@ def test_matches_oracle_at_scale_mutant_shape():
                rotations=torch.randn(P, 4, generator=g), opacity=torch.randn(P, 1, generator=g),
                shs=torch.randn(P, 16, 3, generator=g) * 0.3)
     time, force = torch.full((P, 1), 0.61), torch.zeros(P, 1)
+    # A ReLU input within float32 rounding of zero is a discrete decision that two correct float32
+    # implementations (different summation order) may take differently; one flipped unit of one point moves
+    # a weight gradient by ~1e-3 of its max.  Points whose closest ReLU input is below 1e-5 (|accumulated
+    # rounding| is ~1e-6) are dropped from the comparison set, as the rasterizer tests do with `margin`.
+    cap = {}
+    with torch.no_grad():
+        R.forward_dynamic(sd, cfg, ins["points"], ins["scales"], ins["rotations"], ins["opacity"], ins["shs"], time, force, cap)
+    keep = cap["relu_margin"] >= 1e-5
+    assert keep.float().mean() > 0.9, float(keep.float().mean())
+    ins = {k: v[keep].contiguous() for k, v in ins.items()}
+    P = int(keep.sum())
+    time, force = time[:P], force[:P]
     ws = [torch.randn(s, generator=g) for s in ((P, 3), (P, 3), (P, 4), (P, 1), (P, 16, 3))]
     # oracle
     sdo = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "poc" not in k and "aabb" not in k) for k, v in sd.items()}
