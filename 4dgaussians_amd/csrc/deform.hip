@@ -35,7 +35,7 @@
 #define OC_R 16
 #define OC_SH 24
 #define ROWS_PER_WG 128
-#define GEMM_TARGET_WGS 1024
+#define GEMM_CUS 256
 #define DW_ROWS_PER_WG 512
 #define STRIP_WGS 256           // point runs of the time-plane strip kernel (x3 planes)
 
@@ -575,7 +575,7 @@ struct GemmJob {
     float* Y; int ldy; int ycol0;
     const float* mask; int ldm; int mcol0;         // optional: multiply by (mask > 0)
 };
-struct GemmJobs { GemmJob j[8]; };
+struct GemmJobs { GemmJob j[8]; int wg_begin[9]; };   // job i owns workgroups [wg_begin[i], wg_begin[i+1])
 
 static inline __host__ __device__ int pad8(int v) { return (v + 7) & ~7; }
 static inline __host__ __device__ int gemm_kp(const GemmJob& J)
@@ -585,64 +585,88 @@ static inline __host__ __device__ int gemm_kp(const GemmJob& J)
     return kp;
 }
 
-#define SB_PITCH 65   // row pitch of the staged B operand: conflict-free for the transposing store and the fragment read
 #define GEMM_GB 8     // 8-wide K blocks per register group (one group is in flight while the previous one feeds the MFMAs)
 #define GEMM_MAX_KB 40
 
 // Design: the workgroup stages B (<= 320 x 64) in LDS once and then walks row blocks of 128 (persistent grid);
 // each wave owns 32 rows and streams its A operand straight from global memory into registers: with
 // v_mfma_f32_32x32x2_f32 lane (i, h) supplies A[i][k] for one k per instruction, and since the sum over k
-// may run in any order as long as A and B agree, lane (i, h) takes k = 8m + 4h + s (s = 0..3) of block m --
-// one 16-byte load per block -- while B is read from LDS row 8m + 4h + s.  No LDS round trip and no
-// barrier in the main loop; the next group of blocks (or the next row block) is loaded while the current
-// one is multiplied.
+// may run in any order as long as A and B agree, lane (i, h) takes k = 8m + 4h + q (q = 0..3) of block m --
+// one 16-byte load per block.  B is staged as sB[m][h][j][4] (the four k values lane (j, h) needs from block
+// m are contiguous and neighbouring lanes are 16 bytes apart), so a lane fetches them with one
+// conflict-free ds_read_b128 per column tile.  No LDS round trip for A and no barrier in the main loop;
+// the next group of blocks (or the next row block) is loaded while the current one is multiplied.
+// RELU / MASK are compile-time so the MFMA loop and the epilogue are branch-free; both column tiles are
+// always multiplied (columns >= N are zero in LDS).
+// Measured (C2, rocprofv3): every launch moves 2.2-3.6 TB/s of its own operands -- these layer-by-layer
+// products are bound by HBM traffic, not by the matrix cores (MFMA busy ~46 %).
+template <bool RELU, bool MASK>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 {
     extern __shared__ float smem[];
     __shared__ int s_acol[GEMM_MAX_KB];
-    const GemmJob& J = jobs.j[blockIdx.y];
+    int job_v = 0;
+    while (job_v < 7 && (int)blockIdx.x >= jobs.wg_begin[job_v + 1]) job_v++;
+    const int job = __builtin_amdgcn_readfirstlane(job_v);     // provably uniform: the descriptor is read with scalar loads
+    const GemmJob& J = jobs.j[job];
+    const int wg = blockIdx.x - jobs.wg_begin[job], nwg = jobs.wg_begin[job + 1] - jobs.wg_begin[job];
     const int Kp = gemm_kp(J);
     const int Kb = Kp >> 3;
-    float* sB = smem;                                   // [Kp][SB_PITCH]
+    const int N = J.N;
+    float* sB = smem;                                   // [Kb][2 (k half)][64 (column)][4 (k)]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // ---- stage B (zero rows for A's padding columns) and the A column of every K block
-    for (int kp = tid & 31; kp < Kp; kp += 32) {
-        // padded k -> (segment, local k) -> true k
-        int sg = 0, kl = kp, ktrue = 0;
-        while (sg < J.a_nseg - 1 && kl >= pad8(J.a_len[sg])) { kl -= pad8(J.a_len[sg]); ktrue += J.a_len[sg]; sg++; }
-        const bool kvalid = kl < J.a_len[sg];
-        ktrue += min(kl, J.a_len[sg] - 1);
-        if ((kp & 7) == 0 && tid < 32 * 8) { if ((tid >> 5) == 0) s_acol[kp >> 3] = J.a_beg[sg] + kl; }
-        int bs = 0, bl = ktrue;
-        while (bs < J.b_nseg - 1 && bl >= J.b_rows[bs]) { bl -= J.b_rows[bs]; bs++; }
-        const float* src = J.B[bs];
-        const int ld = J.b_ld[bs], c0 = J.b_col0[bs];
-        float v[8];
+    // ---- stage B (zero rows for A's padding columns) and the A column of every K block.  All of a thread's
+    // loads are issued before its first LDS store, so staging costs about one memory round trip.
+    {
+        float v[GEMM_MAX_KB / 4][8];                    // Kp <= 320: at most 10 rows of k per thread
+        bool kval[GEMM_MAX_KB / 4];
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {                // eight independent loads in flight
-            const int j = min((tid >> 5) + 8 * jj, J.N - 1);
-            v[jj] = J.b_transposed ? src[(size_t)(c0 + j) * ld + bl] : src[(size_t)bl * ld + c0 + j];
+        for (int it = 0; it < GEMM_MAX_KB / 4; it++) {
+            const int kp = (tid & 31) + 32 * it;
+            kval[it] = false;
+            if (kp >= Kp) continue;
+            // padded k -> (segment, local k) -> true k
+            int sg = 0, kl = kp, ktrue = 0;
+            while (sg < J.a_nseg - 1 && kl >= pad8(J.a_len[sg])) { kl -= pad8(J.a_len[sg]); ktrue += J.a_len[sg]; sg++; }
+            kval[it] = kl < J.a_len[sg];
+            ktrue += min(kl, J.a_len[sg] - 1);
+            if ((kp & 7) == 0 && tid < 32) s_acol[kp >> 3] = J.a_beg[sg] + kl;
+            int bs = 0, bl = ktrue;
+            while (bs < J.b_nseg - 1 && bl >= J.b_rows[bs]) { bl -= J.b_rows[bs]; bs++; }
+            const float* src = J.B[bs];
+            const int ld = J.b_ld[bs], c0 = J.b_col0[bs];
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int j = min((tid >> 5) + 8 * jj, N - 1);
+                v[it][jj] = J.b_transposed ? src[(size_t)(c0 + j) * ld + bl] : src[(size_t)bl * ld + c0 + j];
+            }
         }
 #pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const int j = (tid >> 5) + 8 * jj;
-            sB[kp * SB_PITCH + j] = (kvalid && j < J.N) ? v[jj] : 0.f;
+        for (int it = 0; it < GEMM_MAX_KB / 4; it++) {
+            const int kp = (tid & 31) + 32 * it;
+            if (kp >= Kp) continue;
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) {
+                const int j = (tid >> 5) + 8 * jj;
+                sB[(((kp >> 3) * 2 + ((kp >> 2) & 1)) * 64 + j) * 4 + (kp & 3)] = (kval[it] && j < N) ? v[it][jj] : 0.f;
+            }
         }
     }
     __syncthreads();
 
-    const int i = lane & 31, khalf = lane >> 5;
-    const bool two = J.N > 32;
+    const int i = lane & 31, khalf = lane >> 5, col = i;
     const int nrb = (P + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int NG = (Kb + GEMM_GB - 1) / GEMM_GB;
-    const int my_rb = nrb > (int)blockIdx.x ? (nrb - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int my_rb = nrb > wg ? (nrb - 1 - wg) / nwg + 1 : 0;
     const int T = my_rb * NG;                           // flattened (row block, group) steps of this workgroup
+    const float* __restrict__ Abase = J.A;
+    const int lda = J.lda;
 
     auto load_group = [&](int t, float4 (&dst)[GEMM_GB]) {
-        const int rb = blockIdx.x + (t / NG) * gridDim.x, g = t % NG;
+        const int rb = wg + (t / NG) * nwg, g = t % NG;
         const int row = min(rb * ROWS_PER_WG + wave * 32 + i, P - 1);
-        const float* arow = J.A + (size_t)row * J.lda + 4 * khalf;
+        const float* arow = Abase + (size_t)row * lda + 4 * khalf;
 #pragma unroll
         for (int b = 0; b < GEMM_GB; b++) {
             const int m = min(g * GEMM_GB + b, Kb - 1);  // clamped: the surplus blocks of the last group are never multiplied
@@ -651,48 +675,59 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
     };
 
     f32x16 acc0 = {0}, acc1 = {0};
-    const int col = lane & 31;
-    const float bias0 = (J.bias && col < J.N) ? J.bias[col] : 0.f;
-    const float bias1 = (J.bias && col + 32 < J.N) ? J.bias[col + 32] : 0.f;
+    const float bias0 = (J.bias && col < N) ? J.bias[col] : 0.f;
+    const float bias1 = (J.bias && col + 32 < N) ? J.bias[col + 32] : 0.f;
+    float* __restrict__ Y = J.Y + J.ycol0;
+    const int ldy = J.ldy;
+    const float* __restrict__ Mk = MASK ? J.mask + J.mcol0 : nullptr;
+    const int ldm = J.ldm;
+    const float4* sB4 = reinterpret_cast<const float4*>(sB) + khalf * 64 + col;   // + m * 128 (+ 32 for the second tile)
 
     auto compute_group = [&](int t, const float4 (&src)[GEMM_GB]) {
-        const int rb = blockIdx.x + (t / NG) * gridDim.x, g = t % NG;
+        const int rb = wg + (t / NG) * nwg, g = t % NG;
 #pragma unroll
         for (int b = 0; b < GEMM_GB; b++) {
             const int m = g * GEMM_GB + b;
             if (m >= Kb) break;
-            const float av[4] = {src[b].x, src[b].y, src[b].z, src[b].w};
-            const float* brow = sB + (size_t)(8 * m + 4 * khalf) * SB_PITCH + col;
+            const float4 b0 = sB4[m * 128], b1 = sB4[m * 128 + 32];
+            float av[4] = {src[b].x, src[b].y, src[b].z, src[b].w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const float a = J.relu_a ? fmaxf(av[q], 0.f) : av[q];
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[q * SB_PITCH], acc0, 0, 0, 0);
-                if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, brow[q * SB_PITCH + 32], acc1, 0, 0, 0);
+                if (RELU) av[q] = fmaxf(av[q], 0.f);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv1[q], acc1, 0, 0, 0);
             }
         }
         if (g == NG - 1) {
-            // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31
-            const int row0 = rb * ROWS_PER_WG + wave * 32;
+            // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+            // All mask loads are issued before the first store.
+            const int row0 = rb * ROWS_PER_WG + wave * 32 + 4 * khalf;
+            float m0[16], m1[16];
+            if (MASK) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = min(row0 + (r & 3) + 8 * (r >> 2), P - 1);
+                    const float* mrow = Mk + (size_t)row * ldm;
+                    m0[r] = mrow[min(col, N - 1)];
+                    m1[r] = mrow[min(col + 32, N - 1)];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
                 if (row >= P) continue;
-                if (col < J.N) {
-                    float v = acc0[r] + bias0;
-                    if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col] > 0.f)) v = 0.f;
-                    J.Y[(size_t)row * J.ldy + J.ycol0 + col] = v;
-                }
-                if (two && col + 32 < J.N) {
-                    float v = acc1[r] + bias1;
-                    if (J.mask && !(J.mask[(size_t)row * J.ldm + J.mcol0 + col + 32] > 0.f)) v = 0.f;
-                    J.Y[(size_t)row * J.ldy + J.ycol0 + col + 32] = v;
-                }
+                float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+                if (MASK) { v0 = m0[r] > 0.f ? v0 : 0.f; v1 = m1[r] > 0.f ? v1 : 0.f; }
+                if (col < N) Y[(size_t)row * ldy + col] = v0;
+                if (col + 32 < N) Y[(size_t)row * ldy + col + 32] = v1;
             }
             acc0 = (f32x16){0};
             acc1 = (f32x16){0};
         }
     };
 
+    // two register buffers: the next group's loads are in flight while the current one is multiplied
     float4 buf0[GEMM_GB], buf1[GEMM_GB];
     if (T > 0) load_group(0, buf0);
     for (int t = 0; t < T; t += 2) {
@@ -955,7 +990,7 @@ static int validate(const gs4d_deform_desc* d, int P)
     return GS4D_OK;
 }
 
-static size_t gemm_lds_bytes(int Kp) { return (size_t)Kp * SB_PITCH * sizeof(float); }
+static size_t gemm_lds_bytes(int Kp) { return (size_t)Kp * 64 * sizeof(float); }
 
 static int launch_gemm(int P, GemmJobs& jobs, int njobs, hipStream_t s)
 {
@@ -969,14 +1004,36 @@ static int launch_gemm(int P, GemmJobs& jobs, int njobs, hipStream_t s)
         if (!ok) { gs4d_set_error("deform gemm: operand %d violates the 16-byte / pad-8 layout rules", i); return GS4D_EINVAL; }
     }
     const size_t lds = gemm_lds_bytes(Kpmax);
-    static bool attr_set = false;
-    if (!attr_set) {
-        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)gemm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-        attr_set = true;
+    // RELU and MASK are per-launch properties (every job of a launch agrees)
+    const bool relu = jobs.j[0].relu_a != 0, mask = jobs.j[0].mask != nullptr;
+    for (int i = 1; i < njobs; i++)
+        if ((jobs.j[i].relu_a != 0) != relu || (jobs.j[i].mask != nullptr) != mask) {
+            gs4d_set_error("deform gemm: jobs of one launch must agree on ReLU and mask");
+            return GS4D_EINVAL;
+        }
+    void (*kern)(int, GemmJobs) = relu ? (mask ? gemm_rows_kernel<true, true> : gemm_rows_kernel<true, false>)
+                                       : (mask ? gemm_rows_kernel<false, true> : gemm_rows_kernel<false, false>);
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[relu * 2 + mask]) {
+        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
+        attr_set[relu * 2 + mask] = true;
     }
+    // persistent 1-D grid, ~4 workgroups per CU in total (mild oversubscription measured faster than an exactly
+    // resident grid), shared between the jobs in proportion to their MFMA work per row block
     const int nrb = (P + ROWS_PER_WG - 1) / ROWS_PER_WG;
-    const int per_job = (GEMM_TARGET_WGS + njobs - 1) / njobs;       // persistent: ~4 workgroups per CU in total
-    hipLaunchKernelGGL(gemm_rows_kernel, dim3(nrb < per_job ? nrb : per_job, njobs), dim3(256), lds, s, P, jobs);
+    const int total = GEMM_CUS * 4;
+    double wsum = 0, w[8];
+    for (int i = 0; i < njobs; i++) { w[i] = (gemm_kp(jobs.j[i]) / 8) * 2 + 6; wsum += w[i]; }
+    jobs.wg_begin[0] = 0;
+    for (int i = 0; i < 8; i++) {
+        int n = 0;
+        if (i < njobs) {
+            n = (int)(total * w[i] / wsum);
+            n = n < 1 ? 1 : (n > nrb ? nrb : n);
+        }
+        jobs.wg_begin[i + 1] = jobs.wg_begin[i] + n;
+    }
+    hipLaunchKernelGGL(kern, dim3(jobs.wg_begin[8]), dim3(256), lds, s, P, jobs);
     GS4D_LAUNCH_CHECK("deform_gemm", 0, s);
     return GS4D_OK;
 }
