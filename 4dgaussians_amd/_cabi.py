@@ -60,24 +60,57 @@ def current_stream(device) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+_live_allocators = {}          # key -> TensorAllocator, only while its C call is in flight
+_next_key = [1]
+
+
+def _alloc_trampoline(ctx, nbytes):
+    a = _live_allocators.get(ctx)
+    if a is None:
+        return 0
+    try:                        # never let an exception cross the C boundary
+        a._tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=a.device)
+        return a._tensor.data_ptr()
+    except Exception as ex:
+        a.error = ex
+        return 0
+
+
+_TRAMPOLINE = ALLOC_FN(_alloc_trampoline)
+
+
 class TensorAllocator:
-    """gs4d_alloc_fn backed by a growable uint8 torch tensor (the counterpart of the reference's
-    resizeFunctional lambdas, RAST/rasterize_points.cu:27-33)."""
+    """gs4d_alloc_fn backed by a uint8 torch tensor (the counterpart of the reference's resizeFunctional
+    lambdas, RAST/rasterize_points.cu:27-33).  One module-level ctypes thunk serves every call and the
+    allocator is found through its integer context, so no per-call closure / reference cycle is created
+    (cycles kept the scratch tensors alive until the garbage collector ran and cost ~10 % of a step).
+    Pass `.callback` and `.ctx` to the C entry point and call close() when it has returned."""
+    __slots__ = ("device", "_tensor", "error", "_key")
 
     def __init__(self, device):
-        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
-        self.error = None
+        self.device, self._tensor, self.error = device, None, None
+        self._key = _next_key[0]
+        _next_key[0] += 1
+        _live_allocators[self._key] = self
 
-        def _alloc(_ctx, nbytes):
-            try:
-                if self.tensor.numel() < nbytes:
-                    self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
-                return self.tensor.data_ptr()
-            except Exception as ex:  # never let an exception cross the C boundary
-                self.error = ex
-                return 0
+    @property
+    def callback(self):
+        return _TRAMPOLINE
 
-        self.callback = ALLOC_FN(_alloc)
+    @property
+    def ctx(self):
+        return C.c_void_p(self._key)
+
+    @property
+    def tensor(self):
+        if self._tensor is None:
+            self._tensor = torch.empty(0, dtype=torch.uint8, device=self.device)
+        return self._tensor
+
+    def close(self):
+        _live_allocators.pop(self._key, None)
+        if self.error is not None:
+            raise self.error
 
 
 def empty_group(device, *shapes):

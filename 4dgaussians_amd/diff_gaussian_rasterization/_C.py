@@ -49,7 +49,7 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         bg_, means_, sh_, col_, op_, sc_, rot_, cov_, view_, proj_, cam_ = keep
         with torch.cuda.device(device):
             rc = L.gs4d_rasterize_forward(
-                geom.callback, None, binning.callback, None, img.callback, None,
+                geom.callback, geom.ctx, binning.callback, binning.ctx, img.callback, img.ctx,
                 C.c_int(P), C.c_int(int(degree)), C.c_int(M), _cabi.ptr(bg_), C.c_int(W), C.c_int(H),
                 _cabi.ptr(means_), _cabi.ptr(sh_), _cabi.ptr(col_), _cabi.ptr(op_), _cabi.ptr(sc_),
                 C.c_float(scale_modifier), _cabi.ptr(rot_), _cabi.ptr(cov_), _cabi.ptr(view_), _cabi.ptr(proj_),
@@ -57,9 +57,11 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _cabi.ptr(out_color), _cabi.ptr(out_depth), _cabi.ptr(radii), C.c_int(int(bool(debug))),
                 _cabi.current_stream(device), C.byref(rendered))
         for a in (geom, binning, img):
-            if a.error is not None:
-                raise a.error
+            a.close()
         _cabi.check(rc, "rasterize_gaussians")
+    else:
+        for a in (geom, binning, img):
+            a.close()
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
 
 
@@ -83,7 +85,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
         scratch = _cabi.TensorAllocator(device)
         with torch.cuda.device(device):
             rc = L.gs4d_rasterize_backward(
-                scratch.callback, None, C.c_int(P), C.c_int(int(degree)), C.c_int(M), C.c_int(int(R)),
+                scratch.callback, scratch.ctx, C.c_int(P), C.c_int(int(degree)), C.c_int(M), C.c_int(int(R)),
                 _cabi.ptr(bg_), C.c_int(W), C.c_int(H), _cabi.ptr(means_), _cabi.ptr(sh_), _cabi.ptr(col_),
                 _cabi.ptr(sc_), C.c_float(scale_modifier), _cabi.ptr(rot_), _cabi.ptr(cov_), _cabi.ptr(view_),
                 _cabi.ptr(proj_), _cabi.ptr(cam_), C.c_float(tan_fovx), C.c_float(tan_fovy), _cabi.ptr(radii_),
@@ -92,8 +94,7 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
                 _cabi.ptr(dL_dcolors), _cabi.ptr(dL_ddepths), _cabi.ptr(dL_dmeans3D), _cabi.ptr(dL_dcov3D),
                 _cabi.ptr(dL_dsh), _cabi.ptr(dL_dscales), _cabi.ptr(dL_drotations), C.c_int(int(bool(debug))),
                 _cabi.current_stream(device))
-        if scratch.error is not None:
-            raise scratch.error
+        scratch.close()
         _cabi.check(rc, "rasterize_gaussians_backward")
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations
 

@@ -19,9 +19,8 @@ def distCUDA2(points: torch.Tensor) -> torch.Tensor:
     if P:
         scratch = _cabi.TensorAllocator(pts.device)
         with torch.cuda.device(pts.device):
-            rc = L.gs4d_knn_mean_dist2(scratch.callback, None, C.c_int(P), _cabi.ptr(pts), _cabi.ptr(out),
+            rc = L.gs4d_knn_mean_dist2(scratch.callback, scratch.ctx, C.c_int(P), _cabi.ptr(pts), _cabi.ptr(out),
                                        _cabi.current_stream(pts.device))
-        if scratch.error is not None:
-            raise scratch.error
+        scratch.close()
         _cabi.check(rc, "distCUDA2")
     return out

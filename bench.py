@@ -23,6 +23,7 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
 from __future__ import annotations
 
 import argparse
+import gc
 import ctypes as C
 import importlib
 import json
@@ -141,10 +142,19 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # Every recorded HIP event is a barrier packet that costs device idle time (the full 18-stage set cost
+    # ~1.3 ms per step), so the timed region brackets ONLY the dominant kernel's stage; the other stages are
+    # timed in a separate, untimed pass below and reported as diagnostics.
+    dominant = "blend_backward" if args.mode == "train" else "blend_forward"
+    # the set-up above leaves ~1e5 long-lived Python objects; freezing them keeps the cyclic collector's
+    # passes over the young generations cheap (a full collection in the timed region cost ~36 ms once)
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         step()
     sync()
     L.gs4d_profile_reset()
+    L.gs4d_profile_select(None if args.no_stage_events else dominant.encode())
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -157,13 +167,27 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-stage device time from the HIP events recorded in the timed region
-    stages = {}
-    for s in STAGES:
-        ms, calls = C.c_double(0), C.c_long(0)
-        L.gs4d_profile_read(s.encode(), C.byref(ms), C.byref(calls))
-        if calls.value:
-            stages[s] = ms.value / calls.value
+    def read_stages():
+        out = {}
+        for s in STAGES:
+            ms, calls = C.c_double(0), C.c_long(0)
+            L.gs4d_profile_read(s.encode(), C.byref(ms), C.byref(calls))
+            if calls.value:
+                out[s] = ms.value / calls.value
+        return out
+
+    timed = read_stages()                   # the dominant stage, HIP events inside the timed region
+    stages = dict(timed)
+    if not args.no_stage_events:            # every stage, untimed diagnostic pass
+        L.gs4d_profile_reset()
+        L.gs4d_profile_select(None)
+        L.gs4d_profile_enable(1)
+        for _ in range(min(args.steps, 10)):
+            step()
+        sync()
+        L.gs4d_profile_enable(0)
+        stages = read_stages()
+        stages.update(timed)
 
     if rank == 0:
         # workload statistics for the roofline numerators (one extra untimed forward through the C-level API)
@@ -222,6 +246,7 @@ def main():
                        "grad_allreduce_bytes": gauss_bucket.nbytes + deform_bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+            "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
         }
         print(json.dumps(out), flush=True)
     if world > 1:
