@@ -115,6 +115,39 @@ def main():
     cam = R.Camera(cam_np, dev, time=float(rng.uniform(0, 1)), force=0.0)
     bg = torch.ones(3, device=dev)
     target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank))
+    Craw = importlib.import_module("4dgaussians_amd.diff_gaussian_rasterization")._C
+
+    def rasterize_untimed():
+        """One untimed forward through the C-level API -> (num_rendered, state buffers): workload statistics."""
+        with torch.no_grad():
+            m3, sc, rot, op, sh = deform.forward_dynamic(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features,
+                                                         torch.full((P, 1), cam.time, device=dev),
+                                                         torch.zeros(P, 1, device=dev), None)
+            e = torch.Tensor([])
+            return Craw.rasterize_gaussians(
+                bg, m3, e, torch.sigmoid(op), torch.exp(sc), torch.nn.functional.normalize(rot), 1.0, e,
+                cam.world_view_transform, cam.full_proj_transform, cam_np.tanfovx, cam_np.tanfovy, H, W, sh, 3,
+                cam.camera_center, False, False)
+
+    # SURVEY.md 8(d): s0 is chosen per config so that the RENDERED scene has ~8 tiles per Gaussian.  The
+    # random-init deformation heads shift the log-scales, so s0 is calibrated on the deformed scene: a uniform
+    # log-scale offset found by a few fixed-point steps on rank 0's view (tiles ~ scale^2), applied on every rank.
+    log_s0_offset = 0.0
+    for _ in range(8):
+        ratio = rasterize_untimed()[0] / P
+        if abs(ratio - 8.0) < 0.2 or ratio == 0:
+            break
+        d = 0.5 * float(np.log(8.0 / ratio))
+        log_s0_offset += d
+        with torch.no_grad():
+            pc._scaling.add_(d)
+    if world > 1:
+        off = torch.tensor([log_s0_offset], dtype=torch.float64, device=dev)
+        dist.broadcast(off, 0)
+        with torch.no_grad():
+            pc._scaling.add_(float(off.item()) - log_s0_offset)
+        log_s0_offset = float(off.item())
+    raw = dict(raw, log_scales=(raw["log_scales"] + np.float32(log_s0_offset)).astype(np.float32))
     gauss_bucket = par.GradBucket(pc.parameters())
     deform_bucket = par.GradBucket(deform.parameters())
     all_params = list(pc.parameters()) + list(deform.parameters())
@@ -192,15 +225,7 @@ def main():
     if rank == 0:
         # workload statistics for the roofline numerators (one extra untimed forward through the C-level API)
         with torch.no_grad():
-            m3, sc, rot, op, sh = deform.forward_dynamic(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features,
-                                                         torch.full((P, 1), cam.time, device=dev),
-                                                         torch.zeros(P, 1, device=dev), None)
-            Craw = importlib.import_module("4dgaussians_amd.diff_gaussian_rasterization")._C
-            e = torch.Tensor([])
-            Rn, _, _, radii, gb, bb, ib = Craw.rasterize_gaussians(
-                bg, m3, e, torch.sigmoid(op), torch.exp(sc), torch.nn.functional.normalize(rot), 1.0, e,
-                cam.world_view_transform, cam.full_proj_transform, cam_np.tanfovx, cam_np.tanfovy, H, W, sh, 3,
-                cam.camera_center, False, False)
+            Rn, _, _, radii, gb, bb, ib = rasterize_untimed()
             view = Craw.state_view(P, Rn, W, H, gb, bb, ib)
             nc = view["n_contrib"].to(torch.int64)
             gy, gx = (H + 15) // 16, (W + 15) // 16
@@ -255,6 +280,7 @@ def main():
                                    f"{'mutant' if args.config != 'C5' else 'force_blend'}-shaped HexPlane deformation, "
                                    f"1 view per GPU per step", "global_batch_views": world,
                        "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
+                       "log_s0_offset": round(log_s0_offset, 4),
                        "grad_allreduce_bytes": gauss_bucket.nbytes + deform_bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
