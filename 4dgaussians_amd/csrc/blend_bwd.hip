@@ -7,21 +7,33 @@
 // opacity (1).
 //
 // The reference issues 10 global float atomics per contributing (pixel, Gaussian) pair.  Here:
-//  * each wave64 (one 8x8 pixel quadrant) reduces its 64 per-lane contributions with 6 DPP adds
-//    per value and lane 63 stores the wave partial into LDS (one private row per wave: no
-//    LDS atomics);
-//  * after a batch of <= 256 list entries the four wave partials are added in fixed order and
+//  * a workgroup is two wave64; every lane owns TWO horizontally adjacent pixels, so the per-pair
+//    arithmetic runs on the packed-fp32 instructions (v_pk_fma/mul/add_f32: both pixels per issue) --
+//    this kernel is bound by VALU issue, not by memory;
+//  * a pixel that does not blend a Gaussian is not branched around: its alpha and G are replaced by 0,
+//    which turns every state update into the exact identity (T/(1-0), 0*c + 1*acc) and every gradient
+//    term into 0, so the two pixels of a lane never diverge;
+//  * the 10 per-Gaussian sums over the wave's 128 pixels use a transposing reduction:
+//    v_permlane32_swap / v_permlane16_swap halve the lanes AND the number of live values per step
+//    (28 VALU ops per Gaussian instead of 60 DPP adds), ending in three 16-lane DPP reductions;
+//  * lanes 15/31/47/63 store the wave partial into LDS (one private row per wave: no LDS atomics);
+//    a per-wave bit mask records which list entries were written, so nothing is zero-filled;
+//  * after a batch of <= 256 list entries the two wave partials are added in fixed order and
 //    the tile's partial row (12 floats, 10 used) is written to inst_grad[sorted position],
 //    i.e. one coalesced 48-byte row per (tile, Gaussian) instance and NO global atomics;
 //  * the per-Gaussian kernel (geom_bwd.hip) gathers a Gaussian's rows through the inverse
 //    permutation in fixed order, so gradients are bitwise reproducible run to run.
 // Rows of list entries that no pixel of the tile reached (position >= tile_max_contrib) are
-// zero-filled without being evaluated.
+// zero-filled without being evaluated.  1/(1-alpha) uses v_rcp_f32 (1 ulp) where the reference
+// divides; gradient tolerance is 1e-4 relative.
 #include <stdlib.h>
 
 #include "gs4d_internal.h"
 
 namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
 
 template <bool EXACT>
 __device__ __forceinline__ float fast_exp(float x)
@@ -30,47 +42,65 @@ __device__ __forceinline__ float fast_exp(float x)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 
-template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v)
 {
-    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false);
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false);
     return v + __int_as_float(moved);
 }
 
-// Sum over the 64 lanes of the wave; the total is valid in lane 63 only.
-__device__ __forceinline__ float wave_sum_to_lane63(float v)
+// sum over each row of 16 lanes; valid in lanes 12..15 of the row
+__device__ __forceinline__ float row16_sum(float v)
 {
     v = dpp_add<0xB1>(v);             // quad_perm [1,0,3,2]
     v = dpp_add<0x4E>(v);             // quad_perm [2,3,0,1]
     v = dpp_add<0x114>(v);            // row_shr:4
-    v = dpp_add<0x118>(v);            // row_shr:8  -> lanes 12..15 of each row hold the row sum
-    v = dpp_add<0x142, 0xa>(v);       // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);       // row_bcast:31 into rows 2 and 3 -> lane 63 = total
+    v = dpp_add<0x118>(v);            // row_shr:8
     return v;
 }
 
-#define NQ 10  // gradient values per (tile, Gaussian) instance
+// lanes 0..31 receive a[l] + a[l+32], lanes 32..63 receive b[l-32] + b[l]
+__device__ __forceinline__ float fold32(float a, float b)
+{
+    const u2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+// per 32-lane half: its row 0 receives a[row0] + a[row1], its row 1 receives b[row0] + b[row1]
+__device__ __forceinline__ float fold16(float a, float b)
+{
+    const u2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
+#define NQ 10     // gradient values per (tile, Gaussian) instance
+#define NSLOT 12  // LDS slots per instance: slot = 3 * (lane >> 4) + t, see the store below
+#define BWD_THREADS 128
+#define BWD_BATCH 128   // list entries staged per pass (LDS: 5 KB staging + 12 KB partials -> 9 workgroups per CU)
 
 template <bool EXACT>
-__global__ __launch_bounds__(GS4D_TILE_PIX) void blend_backward_kernel(
+__global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const uint32_t* __restrict__ tile_max_contrib, const float* __restrict__ bg, const float2* __restrict__ means2D,
     const float4* __restrict__ conic_opacity, const float* __restrict__ colors, const float* __restrict__ depths,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, float* __restrict__ inst_grad)
 {
-    __shared__ float4 s_a[GS4D_TILE_PIX];   // x, y, conic.x, conic.y
-    __shared__ float4 s_b[GS4D_TILE_PIX];   // conic.z, opacity, depth, r
-    __shared__ float2 s_c[GS4D_TILE_PIX];   // g, b
-    __shared__ float s_part[4][GS4D_TILE_PIX][NQ];  // per-wave partial sums of the current batch (40 KB)
+    __shared__ float4 s_a[BWD_BATCH];   // x, y, conic.x, conic.y
+    __shared__ float4 s_b[BWD_BATCH];   // conic.z, opacity, depth, r
+    __shared__ float2 s_c[BWD_BATCH];   // g, b
+    __shared__ float s_part[2][BWD_BATCH][NSLOT];  // per-wave partial sums of the current batch (24 KB)
+    __shared__ unsigned long long s_mask[2][BWD_BATCH / 64];        // which entries of the batch a wave has written
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int tile = tile_y * gx + tile_x;
-    const int px = tile_x * GS4D_TILE_X + ((wave & 1) << 3) + (lane & 7);
-    const int py = tile_y * GS4D_TILE_Y + ((wave >> 1) << 3) + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
+    // wave -> 8 rows x 16 columns, lane -> two adjacent pixels of a row
+    const int px0 = tile_x * GS4D_TILE_X + 2 * (lane & 7);
+    const int py = tile_y * GS4D_TILE_Y + 8 * wave + (lane >> 3);
+    const bool in0 = px0 < W && py < H, in1 = px0 + 1 < W && py < H;
+    const f2 pxf = {(float)px0, (float)(px0 + 1)};
+    const float pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n_total = (int)(range.y - range.x);
     if (n_total <= 0) return;
@@ -78,128 +108,130 @@ __global__ __launch_bounds__(GS4D_TILE_PIX) void blend_backward_kernel(
 
     float4* __restrict__ rows = reinterpret_cast<float4*>(inst_grad) + (size_t)range.x * (GS4D_GRAD_ROW / 4);
     // zero-fill rows of entries nobody reached
-    for (int i = n_live * (GS4D_GRAD_ROW / 4) + tid; i < n_total * (GS4D_GRAD_ROW / 4); i += GS4D_TILE_PIX)
+    for (int i = n_live * (GS4D_GRAD_ROW / 4) + tid; i < n_total * (GS4D_GRAD_ROW / 4); i += BWD_THREADS)
         rows[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (n_live == 0) return;
 
-    const size_t pix = (size_t)py * W + px;
+    const size_t pix = (size_t)py * W + px0;
     const size_t plane = (size_t)H * W;
-    const float T_final = inside ? final_Ts[pix] : 0.f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix] : 0;
-    float dLp0 = 0.f, dLp1 = 0.f, dLp2 = 0.f, dLpd = 0.f;
-    if (inside) {
-        dLp0 = dL_dpixels[pix];
-        dLp1 = dL_dpixels[plane + pix];
-        dLp2 = dL_dpixels[2 * plane + pix];
-        dLpd = dL_dpixel_depths[pix];
+    f2 T_final = {0.f, 0.f}, dLp0 = {0.f, 0.f}, dLp1 = {0.f, 0.f}, dLp2 = {0.f, 0.f}, dLpd = {0.f, 0.f};
+    int lastc0 = 0, lastc1 = 0;
+    if (in0) {
+        T_final.x = final_Ts[pix]; lastc0 = (int)n_contrib[pix];
+        dLp0.x = dL_dpixels[pix]; dLp1.x = dL_dpixels[plane + pix]; dLp2.x = dL_dpixels[2 * plane + pix];
+        dLpd.x = dL_dpixel_depths[pix];
     }
-    float bg_dot_dpixel = 0.f;
+    if (in1) {
+        T_final.y = final_Ts[pix + 1]; lastc1 = (int)n_contrib[pix + 1];
+        dLp0.y = dL_dpixels[pix + 1]; dLp1.y = dL_dpixels[plane + pix + 1]; dLp2.y = dL_dpixels[2 * plane + pix + 1];
+        dLpd.y = dL_dpixel_depths[pix + 1];
+    }
+    f2 T = T_final;
+    f2 bg_dot_dpixel = {0.f, 0.f};
     bg_dot_dpixel += bg[0] * dLp0;
     bg_dot_dpixel += bg[1] * dLp1;
     bg_dot_dpixel += bg[2] * dLp2;
-    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, accd = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, accd = {0.f, 0.f}, last_alpha = {0.f, 0.f};
+    float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;   // colour / depth of the previous evaluated entry (wave-uniform)
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
 
-    float* part = &s_part[0][0][0];
     // batches walk the live part of the list from the back; each covers positions [lo, lo + n)
-    for (int hi = n_live; hi > 0; hi -= GS4D_TILE_PIX) {
-        const int lo = max(0, hi - GS4D_TILE_PIX);
+    for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
+        const int lo = max(0, hi - BWD_BATCH);
         const int n = hi - lo;
         __syncthreads();  // previous batch's rows have been flushed
-        for (int i = tid; i < 4 * GS4D_TILE_PIX * NQ; i += GS4D_TILE_PIX) part[i] = 0.f;
-        if (tid < n) {
-            const uint32_t id = point_list[range.x + lo + tid];
+        for (int e = tid; e < n; e += BWD_THREADS) {
+            const uint32_t id = point_list[range.x + lo + e];
             const float2 xy = means2D[id];
             const float4 co = conic_opacity[id];
             const float d = depths[id];
             const float r = colors[3 * (size_t)id + 0], g = colors[3 * (size_t)id + 1], b = colors[3 * (size_t)id + 2];
-            s_a[tid] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_b[tid] = make_float4(co.z, co.w, d, r);
-            s_c[tid] = make_float2(g, b);
+            s_a[e] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_b[e] = make_float4(co.z, co.w, d, r);
+            s_c[e] = make_float2(g, b);
         }
         __syncthreads();
 
-        for (int j = n - 1; j >= 0; j--) {
-            const int pos = lo + j;  // 0-based list position == the reference's `contributor` after decrement
-            const float4 a = s_a[j];
-            const float4 b = s_b[j];
-            const float dx = a.x - pxf, dy = a.y - pyf;
-            const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-            const float G = fast_exp<EXACT>(power);
-            const float alpha = fminf(0.99f, b.y * G);
-            const bool use = pos < last_contributor && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-            if (__ballot(use) == 0ull) continue;
+        for (int jb = (n - 1) >> 6; jb >= 0; jb--) {
+            unsigned long long written = 0ull;     // wave-uniform
+            for (int j = min(n - 1, 64 * jb + 63); j >= 64 * jb; j--) {
+                const int pos = lo + j;  // 0-based list position == the reference's `contributor` after decrement
+                const float4 a = s_a[j];
+                const float4 b = s_b[j];
+                const f2 dx = a.x - pxf;
+                const float dy = a.y - pyf;
+                const f2 power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                const f2 G = {fast_exp<EXACT>(power.x), fast_exp<EXACT>(power.y)};
+                const f2 alpha = {fminf(0.99f, b.y * G.x), fminf(0.99f, b.y * G.y)};
+                const bool use0 = pos < lastc0 && !(power.x > 0.0f) && !(alpha.x < (1.0f / 255.0f));
+                const bool use1 = pos < lastc1 && !(power.y > 0.0f) && !(alpha.y < (1.0f / 255.0f));
+                if (__ballot(use0 || use1) == 0ull) continue;
 
-            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, v5 = 0.f, v6 = 0.f, v7 = 0.f, v8 = 0.f, v9 = 0.f;
-            if (use) {
                 const float2 c = s_c[j];
-                const float one_minus_alpha = 1.f - alpha;
-                T = T / one_minus_alpha;
-                const float w = alpha * T;
-                float dL_dalpha = 0.0f;
-                acc0 = last_alpha * lc0 + (1.f - last_alpha) * acc0;
-                lc0 = b.w;
+                // a pixel that skips this entry runs the same arithmetic with alpha = G = 0 (exact identity)
+                const f2 al = {use0 ? alpha.x : 0.f, use1 ? alpha.y : 0.f};
+                const f2 Gm = {use0 ? G.x : 0.f, use1 ? G.y : 0.f};
+                const f2 one_minus_alpha = 1.f - al;
+                const f2 rcp = {__builtin_amdgcn_rcpf(one_minus_alpha.x), __builtin_amdgcn_rcpf(one_minus_alpha.y)};
+                T = T * rcp;
+                const f2 w = al * T;
+                const f2 oml = 1.f - last_alpha;
+                f2 dL_dalpha = {0.f, 0.f};
+                acc0 = last_alpha * lc0 + oml * acc0;
                 dL_dalpha += (b.w - acc0) * dLp0;
-                v0 = w * dLp0;
-                acc1 = last_alpha * lc1 + (1.f - last_alpha) * acc1;
-                lc1 = c.x;
+                acc1 = last_alpha * lc1 + oml * acc1;
                 dL_dalpha += (c.x - acc1) * dLp1;
-                v1 = w * dLp1;
-                acc2 = last_alpha * lc2 + (1.f - last_alpha) * acc2;
-                lc2 = c.y;
+                acc2 = last_alpha * lc2 + oml * acc2;
                 dL_dalpha += (c.y - acc2) * dLp2;
-                v2 = w * dLp2;
-                accd = last_alpha * last_depth + (1.f - last_alpha) * accd;
-                last_depth = b.z;
+                accd = last_alpha * last_depth + oml * accd;
                 dL_dalpha += (b.z - accd) * dLpd;
-                v3 = w * dLpd;
+                lc0 = b.w; lc1 = c.x; lc2 = c.y; last_depth = b.z;
                 dL_dalpha *= T;
-                last_alpha = alpha;
-                dL_dalpha += (-T_final / one_minus_alpha) * bg_dot_dpixel;
-                const float dL_dG = b.y * dL_dalpha;
-                const float gdx = G * dx;
-                const float gdy = G * dy;
-                const float dG_ddelx = -gdx * a.z - gdy * a.w;
-                const float dG_ddely = -gdy * b.x - gdx * a.w;
-                v4 = dL_dG * dG_ddelx * ddelx_dx;
-                v5 = dL_dG * dG_ddely * ddely_dy;
-                v6 = -0.5f * gdx * dx * dL_dG;
-                v7 = -0.5f * gdx * dy * dL_dG;
-                v8 = -0.5f * gdy * dy * dL_dG;
-                v9 = G * dL_dalpha;
+                last_alpha = al;
+                dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
+                const f2 dL_dG = b.y * dL_dalpha;
+                const f2 gdx = Gm * dx;
+                const f2 gdy = Gm * dy;
+                const f2 dG_ddelx = -gdx * a.z - gdy * a.w;
+                const f2 dG_ddely = -gdy * b.x - gdx * a.w;
+                const f2 t = gdx * dL_dG;
+                const f2 p0 = w * dLp0, p1 = w * dLp1, p2 = w * dLp2, p3 = w * dLpd;
+                const f2 p4 = dL_dG * dG_ddelx, p5 = dL_dG * dG_ddely;     // x 0.5 W, 0.5 H at the flush
+                const f2 p6 = t * dx, p7 = t * dy, p8 = gdy * dy * dL_dG;  // x -0.5 at the flush
+                const f2 p9 = Gm * dL_dalpha;
+                // the lane's two pixels, then the transposing reduction over the wave
+                const float u0 = fold32(p0.x + p0.y, p5.x + p5.y);   // lanes <32: v0, >=32: v5
+                const float u1 = fold32(p1.x + p1.y, p6.x + p6.y);   //            v1        v6
+                const float u2 = fold32(p2.x + p2.y, p7.x + p7.y);   //            v2        v7
+                const float u3 = fold32(p3.x + p3.y, p8.x + p8.y);   //            v3        v8
+                const float u4 = fold32(p4.x + p4.y, p9.x + p9.y);   //            v4        v9
+                float t0 = fold16(u0, u1);                           // rows: v0 v1 v5 v6
+                float t1 = fold16(u2, u3);                           // rows: v2 v3 v7 v8
+                float t2 = fold16(u4, u4);                           // rows: v4 v4 v9 v9
+                t0 = row16_sum(t0);
+                t1 = row16_sum(t1);
+                t2 = row16_sum(t2);
+                if ((lane & 15) == 15) {
+                    float* p = &s_part[wave][j][3 * (lane >> 4)];
+                    p[0] = t0; p[1] = t1; p[2] = t2;
+                }
+                written |= 1ull << (j & 63);
             }
-            v0 = wave_sum_to_lane63(v0);
-            v1 = wave_sum_to_lane63(v1);
-            v2 = wave_sum_to_lane63(v2);
-            v3 = wave_sum_to_lane63(v3);
-            v4 = wave_sum_to_lane63(v4);
-            v5 = wave_sum_to_lane63(v5);
-            v6 = wave_sum_to_lane63(v6);
-            v7 = wave_sum_to_lane63(v7);
-            v8 = wave_sum_to_lane63(v8);
-            v9 = wave_sum_to_lane63(v9);
-            if (lane == 63) {
-                float* p = &s_part[wave][j][0];
-                p[0] = v0; p[1] = v1; p[2] = v2; p[3] = v3; p[4] = v4;
-                p[5] = v5; p[6] = v6; p[7] = v7; p[8] = v8; p[9] = v9;
-            }
+            if (lane == 0) s_mask[wave][jb] = written;
         }
         __syncthreads();
-        // flush: fixed-order sum of the four wave partials, one 48-byte row per list entry
-        if (tid < n) {
-            float r_[GS4D_GRAD_ROW];
+        // flush: fixed-order sum of the two wave partials, one 48-byte row per list entry
+        for (int e = tid; e < n; e += BWD_THREADS) {
+            const bool w0 = (s_mask[0][e >> 6] >> (e & 63)) & 1ull, w1 = (s_mask[1][e >> 6] >> (e & 63)) & 1ull;
+            float sl[NSLOT];
 #pragma unroll
-            for (int q = 0; q < NQ; q++)
-                r_[q] = ((s_part[0][tid][q] + s_part[1][tid][q]) + s_part[2][tid][q]) + s_part[3][tid][q];
-            r_[10] = 0.f;
-            r_[11] = 0.f;
-            float4* dst = rows + (size_t)(lo + tid) * (GS4D_GRAD_ROW / 4);
-            dst[0] = make_float4(r_[0], r_[1], r_[2], r_[3]);
-            dst[1] = make_float4(r_[4], r_[5], r_[6], r_[7]);
-            dst[2] = make_float4(r_[8], r_[9], r_[10], r_[11]);
+            for (int q = 0; q < NSLOT; q++) sl[q] = (w0 ? s_part[0][e][q] : 0.f) + (w1 ? s_part[1][e][q] : 0.f);
+            // slots: [v0 v2 v4 | v1 v3 v4 | v5 v7 v9 | v6 v8 v9]
+            float4* dst = rows + (size_t)(lo + e) * (GS4D_GRAD_ROW / 4);
+            dst[0] = make_float4(sl[0], sl[3], sl[1], sl[4]);
+            dst[1] = make_float4(sl[2] * ddelx_dx, sl[6] * ddely_dy, -0.5f * sl[9], -0.5f * sl[7]);
+            dst[2] = make_float4(-0.5f * sl[10], sl[8], 0.f, 0.f);
         }
     }
 }
@@ -214,7 +246,7 @@ int gs4d_launch_blend_backward(int W, int H, int R, const GeomState& g, const Bi
     GS4D_PROF("blend_backward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
-    hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3(gx, gy), dim3(GS4D_TILE_PIX), 0, s, W, H, gx, im.ranges,
+    hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3(gx, gy), dim3(BWD_THREADS), 0, s, W, H, gx, im.ranges,
                        b.point_list(), im.tile_max_contrib, bg, g.means2D, g.conic_opacity, features, g.depths,
                        im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, inst_grad);
     GS4D_LAUNCH_CHECK("blend_backward", debug, s);
