@@ -29,6 +29,7 @@
 #include <stdlib.h>
 
 #include "gs4d_internal.h"
+#include "gs4d_math.h"
 
 namespace {
 
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     __shared__ float4 s_a[BWD_BATCH];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[BWD_BATCH];   // conic.z, opacity, depth, r
     __shared__ float2 s_c[BWD_BATCH];   // g, b
+    __shared__ float4 s_box[BWD_BATCH]; // x - hx, x + hx, y - hy, y + hy: where alpha can reach 1/255
     __shared__ float s_part[2][BWD_BATCH][NSLOT];  // per-wave partial sums of the current batch (24 KB)
     __shared__ unsigned long long s_mask[2][BWD_BATCH / 64];        // which entries of the batch a wave has written
 
@@ -101,6 +103,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const bool in0 = px0 < W && py < H, in1 = px0 + 1 < W && py < H;
     const f2 pxf = {(float)px0, (float)(px0 + 1)};
     const float pyf = (float)py;
+    // the wave's pixel rectangle (pixel coordinates are integers)
+    const float rx0 = (float)(tile_x * GS4D_TILE_X), rx1 = rx0 + (float)(GS4D_TILE_X - 1);
+    const float ry0 = (float)(tile_y * GS4D_TILE_Y + 8 * wave), ry1 = ry0 + 7.0f;
     const uint2 range = ranges[tile];
     const int n_total = (int)(range.y - range.x);
     if (n_total <= 0) return;
@@ -150,12 +155,27 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             s_a[e] = make_float4(xy.x, xy.y, co.x, co.y);
             s_b[e] = make_float4(co.z, co.w, d, r);
             s_c[e] = make_float2(g, b);
+            s_box[e] = gs4d::alpha_support_box(xy, co);
         }
         __syncthreads();
 
         for (int jb = (n - 1) >> 6; jb >= 0; jb--) {
+            // entries whose alpha support misses this wave's 16 x 8 pixels are never visited (see blend_fwd.hip)
+            unsigned long long todo;
+            {
+                const int e = 64 * jb + lane;
+                bool hit = false;
+                if (e < n) {
+                    const float4 bx = s_box[e];
+                    hit = bx.x <= rx1 && bx.y >= rx0 && bx.z <= ry1 && bx.w >= ry0;
+                }
+                todo = __ballot(hit);
+            }
             unsigned long long written = 0ull;     // wave-uniform
-            for (int j = min(n - 1, 64 * jb + 63); j >= 64 * jb; j--) {
+            while (todo != 0ull) {
+                const int jl = 63 - __builtin_clzll(todo);
+                todo &= ~(1ull << jl);
+                const int j = 64 * jb + jl;
                 const int pos = lo + j;  // 0-based list position == the reference's `contributor` after decrement
                 const float4 a = s_a[j];
                 const float4 b = s_b[j];

@@ -7,8 +7,11 @@
 // term), final T and n_contrib = list position of the pixel's last contributor.
 //
 // gfx950 design:
-//  * one workgroup = one tile = 4 wave64; each wave owns an 8x8 pixel quadrant (better wave-level
-//    coherence for early termination than 16x4 strips; results do not depend on the mapping);
+//  * one workgroup = one tile = 2 wave64; a wave owns 8 rows x 16 columns and every lane TWO
+//    horizontally adjacent pixels, so the per-pair arithmetic runs on the packed-fp32 instructions
+//    (v_pk_fma/mul/add_f32: both pixels per issue) -- the kernel is bound by VALU issue, not memory;
+//  * a pixel that does not blend a Gaussian runs the same arithmetic with alpha = 0 (exact identity:
+//    w = 0, T * (1 - 0)), so the two pixels of a lane never diverge;
 //  * each batch of 256 list entries is gathered ONCE per tile into LDS as three arrays
 //    (xy+conic.xy | conic.z,opacity,depth,r | g,b) so the inner loop issues two broadcast
 //    ds_read_b128 for the alpha test and touches the colour words only when some lane of the
@@ -19,8 +22,11 @@
 #include <stdlib.h>
 
 #include "gs4d_internal.h"
+#include "gs4d_math.h"
 
 namespace {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <bool EXACT>
 __device__ __forceinline__ float fast_exp(float x)
@@ -29,8 +35,10 @@ __device__ __forceinline__ float fast_exp(float x)
     return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
 }
 
+#define FWD_THREADS 128
+
 template <bool EXACT>
-__global__ __launch_bounds__(GS4D_TILE_PIX) void blend_forward_kernel(
+__global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ means2D, const float* __restrict__ features, const float* __restrict__ depths,
     const float4* __restrict__ conic_opacity, const float* __restrict__ bg, float* __restrict__ final_T,
@@ -40,96 +48,131 @@ __global__ __launch_bounds__(GS4D_TILE_PIX) void blend_forward_kernel(
     __shared__ float4 s_a[GS4D_TILE_PIX];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[GS4D_TILE_PIX];   // conic.z, opacity, depth, r
     __shared__ float2 s_c[GS4D_TILE_PIX];   // g, b
-    __shared__ int s_wave_done[4];
-    __shared__ uint32_t s_wave_max[4];
+    __shared__ float4 s_box[GS4D_TILE_PIX]; // x - hx, x + hx, y - hy, y + hy: where alpha can reach 1/255
+    __shared__ int s_wave_done[2];
+    __shared__ uint32_t s_wave_max[2];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    // wave -> 8x8 quadrant, lane -> pixel inside it
-    const int px = tile_x * GS4D_TILE_X + ((wave & 1) << 3) + (lane & 7);
-    const int py = tile_y * GS4D_TILE_Y + ((wave >> 1) << 3) + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
+    // wave -> 8 rows x 16 columns, lane -> two adjacent pixels of a row
+    const int px0 = tile_x * GS4D_TILE_X + 2 * (lane & 7);
+    const int py = tile_y * GS4D_TILE_Y + 8 * wave + (lane >> 3);
+    const bool in0 = px0 < W && py < H, in1 = px0 + 1 < W && py < H;
+    const f2 pxf = {(float)px0, (float)(px0 + 1)};
+    const float pyf = (float)py;
+    // the wave's pixel rectangle (pixel coordinates are integers)
+    const float rx0 = (float)(tile_x * GS4D_TILE_X), rx1 = rx0 + (float)(GS4D_TILE_X - 1);
+    const float ry0 = (float)(tile_y * GS4D_TILE_Y + 8 * wave), ry1 = ry0 + 7.0f;
 
     const uint2 range = ranges[tile_y * gx + tile_x];
     const int n_total = (int)(range.y - range.x);
 
-    bool done = !inside;
-    float T = 1.0f;
-    float C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f;
-    uint32_t last_contributor = 0;
+    bool done0 = !in0, done1 = !in1;
+    f2 T = {1.0f, 1.0f};
+    f2 C0 = {0.f, 0.f}, C1 = {0.f, 0.f}, C2 = {0.f, 0.f}, Dp = {0.f, 0.f};
+    uint32_t last0 = 0, last1 = 0;
 
     for (int base = 0; base < n_total; base += GS4D_TILE_PIX) {
         // tile-wide early exit: every wave publishes whether all of its pixels are finished
-        const bool wave_done = __ballot(!done) == 0ull;
+        const bool wave_done = __ballot(!done0 || !done1) == 0ull;
         if (lane == 0) s_wave_done[wave] = wave_done;
         __syncthreads();
-        if (s_wave_done[0] & s_wave_done[1] & s_wave_done[2] & s_wave_done[3]) break;
+        if (s_wave_done[0] & s_wave_done[1]) break;
 
         const int n = min(GS4D_TILE_PIX, n_total - base);
-        if (tid < n) {
-            const uint32_t id = point_list[range.x + base + tid];
+        for (int e = tid; e < n; e += FWD_THREADS) {
+            const uint32_t id = point_list[range.x + base + e];
             const float2 xy = means2D[id];
             const float4 co = conic_opacity[id];
             const float d = depths[id];
             const float r = features[3 * (size_t)id + 0], g = features[3 * (size_t)id + 1],
                         b = features[3 * (size_t)id + 2];
-            s_a[tid] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_b[tid] = make_float4(co.z, co.w, d, r);
-            s_c[tid] = make_float2(g, b);
+            s_a[e] = make_float4(xy.x, xy.y, co.x, co.y);
+            s_b[e] = make_float4(co.z, co.w, d, r);
+            s_c[e] = make_float2(g, b);
+            s_box[e] = gs4d::alpha_support_box(xy, co);
         }
         __syncthreads();
 
         if (!wave_done) {
-            for (int j = 0; j < n; j++) {
-                const float4 a = s_a[j];
-                const float4 b = s_b[j];
-                const float dx = a.x - pxf, dy = a.y - pyf;
-                const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-                const float alpha = fminf(0.99f, b.y * fast_exp<EXACT>(power));
-                const float test_T = T * (1.0f - alpha);
-                bool use = !done && !(power > 0.0f) && !(alpha < (1.0f / 255.0f));
-                if (use && test_T < 0.0001f) {
-                    done = true;
-                    use = false;
+            // Which entries can reach alpha >= 1/255 somewhere in this wave's 16 x 8 pixels?  One entry per lane
+            // is tested against the wave's rectangle, the ballots are wave-uniform bit masks, and the blend loop
+            // walks their set bits: an entry whose support misses the rectangle costs nothing at all.
+            unsigned long long hits[GS4D_TILE_PIX / 64];
+#pragma unroll
+            for (int k = 0; k < GS4D_TILE_PIX / 64; k++) {
+                const int e = 64 * k + lane;
+                bool hit = false;
+                if (e < n) {
+                    const float4 bx = s_box[e];
+                    hit = bx.x <= rx1 && bx.y >= rx0 && bx.z <= ry1 && bx.w >= ry0;
                 }
-                if (__ballot(use) != 0ull) {
-                    const float2 c = s_c[j];
-                    if (use) {
-                        const float w = alpha * T;
+                hits[k] = __ballot(hit);
+            }
+            bool all_done = false;
+#pragma unroll
+            for (int k = 0; k < GS4D_TILE_PIX / 64; k++) {
+                unsigned long long m = hits[k];
+                while (m != 0ull && !all_done) {
+                    const int j = 64 * k + __builtin_ctzll(m);
+                    m &= m - 1;
+                    const float4 a = s_a[j];
+                    const float4 b = s_b[j];
+                    const f2 dx = a.x - pxf;
+                    const float dy = a.y - pyf;
+                    const f2 power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+                    const f2 alpha = {fminf(0.99f, b.y * fast_exp<EXACT>(power.x)), fminf(0.99f, b.y * fast_exp<EXACT>(power.y))};
+                    const f2 test_T = T * (1.0f - alpha);
+                    bool use0 = !done0 && !(power.x > 0.0f) && !(alpha.x < (1.0f / 255.0f));
+                    bool use1 = !done1 && !(power.y > 0.0f) && !(alpha.y < (1.0f / 255.0f));
+                    if (use0 && test_T.x < 0.0001f) { done0 = true; use0 = false; }
+                    if (use1 && test_T.y < 0.0001f) { done1 = true; use1 = false; }
+                    if (__ballot(use0 || use1) != 0ull) {
+                        const float2 c = s_c[j];
+                        const f2 al = {use0 ? alpha.x : 0.f, use1 ? alpha.y : 0.f};   // skip == blend with alpha 0
+                        const f2 w = al * T;
                         C0 += b.w * w;
                         C1 += c.x * w;
                         C2 += c.y * w;
                         Dp += b.z * w;
-                        T = test_T;
-                        last_contributor = (uint32_t)(base + j + 1);
+                        T.x = use0 ? test_T.x : T.x;
+                        T.y = use1 ? test_T.y : T.y;
+                        last0 = use0 ? (uint32_t)(base + j + 1) : last0;
+                        last1 = use1 ? (uint32_t)(base + j + 1) : last1;
+                    } else if (__ballot(!done0 || !done1) == 0ull) {
+                        all_done = true;  // every pixel of this wave is finished
                     }
-                } else if (__ballot(!done) == 0ull) {
-                    break;  // every pixel of this wave is finished
                 }
             }
         }
         __syncthreads();  // the staging arrays are rewritten by the next batch
     }
 
-    if (inside) {
-        const size_t pix = (size_t)py * W + px;
-        const size_t plane = (size_t)H * W;
-        final_T[pix] = T;
-        n_contrib[pix] = last_contributor;
-        out_color[pix] = C0 + T * bg[0];
-        out_color[plane + pix] = C1 + T * bg[1];
-        out_color[2 * plane + pix] = C2 + T * bg[2];
-        out_depth[pix] = Dp;
+    const size_t pix = (size_t)py * W + px0;
+    const size_t plane = (size_t)H * W;
+    if (in0) {
+        final_T[pix] = T.x;
+        n_contrib[pix] = last0;
+        out_color[pix] = C0.x + T.x * bg[0];
+        out_color[plane + pix] = C1.x + T.x * bg[1];
+        out_color[2 * plane + pix] = C2.x + T.x * bg[2];
+        out_depth[pix] = Dp.x;
+    }
+    if (in1) {
+        final_T[pix + 1] = T.y;
+        n_contrib[pix + 1] = last1;
+        out_color[pix + 1] = C0.y + T.y * bg[0];
+        out_color[plane + pix + 1] = C1.y + T.y * bg[1];
+        out_color[2 * plane + pix + 1] = C2.y + T.y * bg[2];
+        out_depth[pix + 1] = Dp.y;
     }
     // per-tile maximum of n_contrib: lets the backward skip list entries no pixel reached
-    uint32_t m = inside ? last_contributor : 0u;
+    uint32_t m = max(in0 ? last0 : 0u, in1 ? last1 : 0u);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
     if (lane == 0) s_wave_max[wave] = m;
     __syncthreads();
-    if (tid == 0)
-        tile_max_contrib[tile_y * gx + tile_x] = max(max(s_wave_max[0], s_wave_max[1]), max(s_wave_max[2], s_wave_max[3]));
+    if (tid == 0) tile_max_contrib[tile_y * gx + tile_x] = max(s_wave_max[0], s_wave_max[1]);
 }
 
 }  // namespace
@@ -141,7 +184,7 @@ int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningSta
     GS4D_PROF("blend_forward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
-    hipLaunchKernelGGL(exact ? blend_forward_kernel<true> : blend_forward_kernel<false>, dim3(gx, gy), dim3(GS4D_TILE_PIX), 0, s, W, H, gx, im.ranges,
+    hipLaunchKernelGGL(exact ? blend_forward_kernel<true> : blend_forward_kernel<false>, dim3(gx, gy), dim3(FWD_THREADS), 0, s, W, H, gx, im.ranges,
                        b.point_list(), g.means2D, features, g.depths, g.conic_opacity, bg, im.final_T, im.n_contrib,
                        im.tile_max_contrib, out_color, out_depth);
     GS4D_LAUNCH_CHECK("blend_forward", debug, s);

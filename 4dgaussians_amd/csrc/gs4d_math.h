@@ -144,4 +144,24 @@ __device__ __forceinline__ Mat3 scale_columns(const float3 s)
     return mat3_from_columns(s.x, 0.f, 0.f, 0.f, s.y, 0.f, 0.f, 0.f, s.z);
 }
 
+// Axis-aligned box around a splat outside of which alpha = opacity * exp(power) < 1/255 for certain, i.e.
+// where both blend kernels skip the splat (forward.cu:343-346, backward.cu:515-518 of the reference).
+// alpha >= 1/255  <=>  0.5 (cx dx^2 + 2 cy dx dy + cz dy^2) <= t,  t = ln(255 opacity); the ellipse's
+// half extents are sqrt(2 t cz / det) and sqrt(2 t cx / det), det = cx cz - cy^2.  The box is inflated
+// (0.1 % + 0.05 px) so float rounding in the kernels' own alpha can never disagree with it; a splat
+// that cannot reach 1/255 anywhere gets an empty box.  Returns (x - hx, x + hx, y - hy, y + hy).
+__device__ __forceinline__ float4 alpha_support_box(float2 xy, float4 conic_opacity)
+{
+    const float cx = conic_opacity.x, cy = conic_opacity.y, cz = conic_opacity.z;
+    const float t = logf(255.0f * conic_opacity.w);
+    const float det = cx * cz - cy * cy;
+    if (!(t > 0.0f) || !(det > 0.0f)) {
+        if (t > 0.0f) return make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);   // degenerate conic: never cull
+        return make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
+    }
+    const float k = 2.0f * t / det;
+    const float hx = sqrtf(k * cz) * 1.001f + 0.05f, hy = sqrtf(k * cx) * 1.001f + 0.05f;
+    return make_float4(xy.x - hx, xy.x + hx, xy.y - hy, xy.y + hy);
+}
+
 }  // namespace gs4d
