@@ -226,3 +226,18 @@ def test_float32_summation_noise_floor_of_the_reference_algorithm():
         assert rel[k] < 2e-5, (k, rel[k])
     assert 2e-5 < rel["dL_drotations"] < 3e-4, rel["dL_drotations"]
     assert rel["dL_dscales"] < 3e-4
+
+
+def test_mat3_helpers_match_vendored_glm_bit_for_bit():
+    """oracle/glm_check.cpp: the oracle's mat3 product / transpose against the glm headers vendored in the
+    reference tree (container only: skipped where /root/reference is absent, e.g. on the GPU box)."""
+    import os
+    import subprocess
+    glm = "/root/reference/submodules/depth-diff-gaussian-rasterization/third_party/glm/glm/glm.hpp"
+    if not os.path.exists(glm):
+        pytest.skip("reference tree not present")
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle")
+    subprocess.run(["make", "-C", root, "ref"], check=True, capture_output=True)
+    out = subprocess.run([os.path.join(root, "_ref", "glm_check")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 mismatching" in out.stdout
