@@ -578,6 +578,7 @@ struct GemmJob {
 struct GemmJobs { GemmJob j[8]; int wg_begin[9]; };   // job i owns workgroups [wg_begin[i], wg_begin[i+1])
 
 static inline __host__ __device__ int pad8(int v) { return (v + 7) & ~7; }
+static inline __host__ __device__ int pad4(int v) { return (v + 3) & ~3; }
 static inline __host__ __device__ int gemm_kp(const GemmJob& J)
 {
     int kp = 0;
@@ -743,91 +744,192 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 struct DwJob {
     const float* G; int ldg; int gcol0; int N;
     const float* X; int ldx; int x_nseg; int x_beg[3]; int x_len[3]; int K; int relu_x;
+    int Kp;                              // K with every segment padded to 4 columns (the staged / slab k space; the source pads with zeros)
     float* slabs; int kblocks;           // kblocks = ceil((K+1)/32); slab row pitch = 32*kblocks
     float* dW; float* db;                // final destinations [N][K], [N]
 };
-struct DwJobs { DwJob j[16]; };
+struct DwJobs { DwJob j[16]; int njobs, nz, nchunks; };
 
-// Each wave owns one 32-row block of n and three 32-column blocks of k; per step it fetches 16 point rows
-// (8 MFMA k-steps) of its G and X columns straight from global memory -- every load is a coalesced
-// 128-byte row segment per half-wave -- one step ahead of the MFMAs that consume them.
-#define DW_STEP 8   // MFMA k-steps (pairs of point rows) per register block
+// One workgroup = one (chunk of DW_ROWS_PER_WG point rows, job, slice of <= 6 k-blocks).  The rows are staged
+// through LDS in sub-blocks of DW_RB (every element of G and X is fetched from memory exactly once per
+// workgroup, coalesced, with ReLU / the bias column of ones / zero padding applied at the store), double
+// buffered, and the (n-block, k-block) output tiles are dealt round-robin to the four waves; both MFMA
+// operands are plain ds_read_b32 (row pitches are 32 mod 64 floats, so the two k halves of a wave use
+// disjoint banks).  The earlier version fetched operands per wave straight from global memory: every G block
+// was read by two waves and every X block by two more, 1.8 GB of L2 traffic per step for 0.4 GB of data.
+#define DW_RB 16
+#define DW_GP 96
+#define DW_XP 224
+#define DW_XCOLS 192
 __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
 {
-    const DwJob& J = jobs.j[blockIdx.y];
+    __shared__ float sG[2][DW_RB * DW_GP];
+    __shared__ float sX[2][DW_RB * DW_XP];
+    __shared__ int s_xcol[DW_XCOLS / 4];
+    // 1-D grid, XCD-aware: consecutive workgroup ids go to different XCDs (each with its own L2), so the
+    // jobs of one chunk -- which re-read the same rows of Z / dH1 / H1 / dO -- are placed 8 ids apart:
+    // same XCD, adjacent in dispatch order.
+    const int id = blockIdx.x;
+    const int rest = id >> 3;
+    const int job_v = rest % jobs.njobs;
+    const int rest2 = rest / jobs.njobs;
+    const int zblk = rest2 % jobs.nz;
+    const int chunk = (rest2 / jobs.nz) * 8 + (id & 7);
+    if (chunk >= jobs.nchunks) return;
+    const DwJob& J = jobs.j[__builtin_amdgcn_readfirstlane(job_v)];
+    const int kb_first = zblk * 6;
+    const int nkb = min(6, J.kblocks - kb_first);
+    if (nkb <= 0) return;                                   // uniform
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nblk = wave & 1;
-    const int kb0 = blockIdx.z * 6 + (wave >> 1);   // this wave's k-blocks: kb0, kb0+2, kb0+4
-    if ((nblk * 32 >= J.N) || kb0 >= J.kblocks) return;
-    const int rbeg = blockIdx.x * DW_ROWS_PER_WG, rend = min(P, rbeg + DW_ROWS_PER_WG);
-    const int n = nblk * 32 + (lane & 31);
-    const int half = lane >> 5;
-    const bool nok = n < J.N;
-    const float* gsrc = J.G + J.gcol0 + min(n, J.N - 1);
-    const float* xsrc[3]; bool xone[3], xok[3];
-#pragma unroll
-    for (int t = 0; t < 3; t++) {
-        const int k = (kb0 + 2 * t) * 32 + (lane & 31);
-        xone[t] = (k == J.K);
-        xok[t] = (kb0 + 2 * t) < J.kblocks && k < J.K;
-        int kl = min(k, J.K - 1), s = 0;
-        while (s < J.x_nseg - 1 && kl >= J.x_len[s]) { kl -= J.x_len[s]; s++; }
-        xsrc[t] = J.X + J.x_beg[s] + kl;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int nn = (J.N + 31) >> 5;                         // 1 or 2 n-blocks
+    const int ntiles = nn * nkb;                            // <= 12; wave w owns tiles w, w+4, w+8 (all with n-block w % nn)
+    const int cnt = (ntiles - wave + 3) >> 2;
+    const int nb = wave % nn;
+    const int rbeg = chunk * DW_ROWS_PER_WG, rend = min(P, rbeg + DW_ROWS_PER_WG);
+
+    // staged 4-column group -> source column of X.  Segments begin on 4-float boundaries and every segment but
+    // the last is a multiple of 4 long (checked on the host), so a group is one aligned float4 of the source row;
+    // the group holding column K is patched per component (ones for the bias column, zeros after it; the
+    // source row is padded, so the over-read stays inside it).  -1: group is entirely past K.
+    for (int c = tid; c < DW_XCOLS / 4; c += 256) {
+        const int k = kb_first * 32 + 4 * c;
+        int src = -1;
+        if (4 * c < nkb * 32 && k < J.Kp) {
+            int kl = k, sg = 0;
+            while (sg < J.x_nseg - 1 && kl >= pad4(J.x_len[sg])) { kl -= pad4(J.x_len[sg]); sg++; }
+            src = J.x_beg[sg] + kl;
+        }
+        s_xcol[c] = src;
     }
-    float a_n[DW_STEP], b_n[3][DW_STEP];
-    auto fetch = [&](int r) {
+    __syncthreads();
+    // fixed staging assignments of this thread: one float4 of G (16 rows x 16 groups), three of X (16 x 48)
+    int xoff[3], xrow[3], xdst[3], xk[3];
+    bool xlive[3];
 #pragma unroll
-        for (int s = 0; s < DW_STEP; s++) {
-            const int row = min(r + 2 * s + half, rend - 1);      // clamped: validity is applied at consumption
-            a_n[s] = gsrc[(size_t)row * J.ldg];
+    for (int i = 0; i < 3; i++) {
+        const int e = tid + 256 * i;
+        const int row = e / (DW_XCOLS / 4), grp = e - row * (DW_XCOLS / 4);
+        xrow[i] = row;
+        xoff[i] = s_xcol[grp];
+        xdst[i] = row * DW_XP + 4 * grp;
+        xk[i] = kb_first * 32 + 4 * grp;                    // k of the group's first column
+        xlive[i] = 4 * grp < nkb * 32;                      // groups of k-blocks this slice does not own are never read
+    }
+    const int ggrp = tid & 15, grow = tid >> 4;             // G: row grow, columns 4*ggrp .. +3
+    const float* __restrict__ Gp = J.G + J.gcol0 + 4 * min(ggrp, (J.N - 1) >> 2);
+    const float* __restrict__ Xp = J.X;
+    const int ldg = J.ldg, ldx = J.ldx, N = J.N, K = J.Kp;
+    const bool relu = J.relu_x != 0;
+
+    float4 gv, xv[3];
+    auto fetch = [&](int r0) {
+        gv = *reinterpret_cast<const float4*>(Gp + (size_t)min(r0 + grow, rend - 1) * ldg);
 #pragma unroll
-            for (int t = 0; t < 3; t++) b_n[t][s] = xsrc[t][(size_t)row * J.ldx];
+        for (int i = 0; i < 3; i++)
+            if (xlive[i] && xoff[i] >= 0)
+                xv[i] = *reinterpret_cast<const float4*>(Xp + (size_t)min(r0 + xrow[i], rend - 1) * ldx + xoff[i]);
+    };
+    auto stash = [&](int r0, int buf) {
+        const bool rok = r0 + grow < rend;
+        float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) g4[q] = (rok && 4 * ggrp + q < N) ? g4[q] : 0.f;
+        *reinterpret_cast<float4*>(&sG[buf][grow * DW_GP + 4 * ggrp]) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (!xlive[i]) continue;
+            float x4[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int k = xk[i] + q;
+                float v = relu ? fmaxf(x4[q], 0.f) : x4[q];
+                x4[q] = (xoff[i] >= 0 && k < K) ? v : (k == K ? 1.f : 0.f);
+            }
+            *reinterpret_cast<float4*>(&sX[buf][xdst[i]]) = make_float4(x4[0], x4[1], x4[2], x4[3]);
         }
     };
+
     f32x16 acc[3] = {{0}, {0}, {0}};
     fetch(rbeg);
-    for (int r = rbeg; r < rend; r += 2 * DW_STEP) {
-        float a_c[DW_STEP], b_c[3][DW_STEP];
+    stash(rbeg, 0);
+    __syncthreads();
+    int buf = 0;
+    for (int r = rbeg; r < rend; r += DW_RB, buf ^= 1) {
+        const bool more = r + DW_RB < rend;
+        if (more) fetch(r + DW_RB);
+        if (cnt > 0) {
+            const float* ga = &sG[buf][half * DW_GP + nb * 32 + l31];
+            const float* xb = &sX[buf][half * DW_XP + (wave / nn) * 32 + l31];
+            const int kstep = (4 / nn) * 32;                // k-block distance between the wave's consecutive tiles
 #pragma unroll
-        for (int s = 0; s < DW_STEP; s++) {
-            const bool ok = r + 2 * s + half < rend;
-            a_c[s] = (ok && nok) ? a_n[s] : 0.f;
-#pragma unroll
-            for (int t = 0; t < 3; t++) {
-                float b = xok[t] ? (J.relu_x ? fmaxf(b_n[t][s], 0.f) : b_n[t][s]) : (xone[t] ? 1.f : 0.f);
-                b_c[t][s] = ok ? b : 0.f;
+            for (int st = 0; st < DW_RB / 2; st++) {
+                const float a = ga[2 * st * DW_GP];
+                const float b0 = xb[2 * st * DW_XP];
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                if (cnt > 1) {
+                    const float b1 = xb[2 * st * DW_XP + kstep];
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                }
+                if (cnt > 2) {
+                    const float b2 = xb[2 * st * DW_XP + 2 * kstep];
+                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+                }
             }
         }
-        if (r + 2 * DW_STEP < rend) fetch(r + 2 * DW_STEP);
-#pragma unroll
-        for (int s = 0; s < DW_STEP; s++)
-#pragma unroll
-            for (int t = 0; t < 3; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c[s], b_c[t][s], acc[t], 0, 0, 0);
+        if (more) stash(r + DW_RB, buf ^ 1);
+        __syncthreads();
     }
     const int pitch = 32 * J.kblocks;
-    float* slab = J.slabs + (size_t)blockIdx.x * 64 * pitch;
+    float* slab = J.slabs + (size_t)chunk * 64 * pitch;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
-        if (kb0 + 2 * t >= J.kblocks) continue;
+        if (t >= cnt) continue;
+        const int kb = kb_first + wave / nn + t * (4 / nn);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int nn = nblk * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            slab[(size_t)nn * pitch + (kb0 + 2 * t) * 32 + (lane & 31)] = acc[t][r];
+            const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            slab[(size_t)n * pitch + kb * 32 + l31] = acc[t][r];
         }
     }
 }
 
 __global__ __launch_bounds__(256) void dw_reduce_kernel(int nchunks, DwJobs jobs)
 {
+    __shared__ float part[4][64];
     const DwJob& J = jobs.j[blockIdx.y];
     const int pitch = 32 * J.kblocks;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= J.N * (J.K + 1)) return;
-    const int n = idx / (J.K + 1), k = idx % (J.K + 1);
+    const int o = threadIdx.x & 63, q = threadIdx.x >> 6;          // output of the block, chunk quarter
+    const int idx = blockIdx.x * 64 + o;
+    const int total = J.N * (J.K + 1);
+    if (blockIdx.x * 64 >= total) return;                          // uniform
+    const int n = min(idx, total - 1) / (J.K + 1), k = min(idx, total - 1) % (J.K + 1);
+    const int per = (nchunks + 3) / 4;
+    const int cbeg = q * per, cend = min(nchunks, cbeg + per);
+    int kpad = J.Kp;                                               // the bias column
+    if (k < J.K) {
+        int kl = k, sg = 0;
+        kpad = 0;
+        while (sg < J.x_nseg - 1 && kl >= J.x_len[sg]) { kl -= J.x_len[sg]; kpad += pad4(J.x_len[sg]); sg++; }
+        kpad += kl;
+    }
+    const float* __restrict__ src = J.slabs + (size_t)n * pitch + kpad;
+    const size_t cstride = (size_t)64 * pitch;
     float s = 0.f;
-    for (int c = 0; c < nchunks; c++) s += J.slabs[((size_t)c * 64 + n) * pitch + k];
-    if (k == J.K) J.db[n] += s;
-    else J.dW[(size_t)n * J.K + k] += s;
+    for (int c = cbeg; c < cend; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = src[(size_t)min(c + u, cend - 1) * cstride];
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += (c + u < cend) ? v[u] : 0.f;
+    }
+    part[q][o] = s;
+    __syncthreads();
+    if (q == 0 && idx < total) {
+        const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
+        if (k == J.K) J.db[n] += t;
+        else J.dW[(size_t)n * J.K + k] += t;
+    }
 }
 
 // ------------------------------------------------------------------ residual outputs
@@ -1069,7 +1171,7 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     gs4d_obtain(p, *dO, P * OUT_LD);
     gs4d_obtain(p, *dH1, P * NHEAD * WIDTH);
     gs4d_obtain(p, *dZ, P * l.ldz);
-    gs4d_obtain(p, *dT, P * WIDTH * 2);
+    gs4d_obtain(p, *dT, P * WIDTH * (size_t)(d->trunk_layers > 1 ? d->trunk_layers - 1 : 1));   // one buffer per inner trunk layer (all stay live for the single weight-gradient launch)
     gs4d_obtain(p, *dfeat, P * l.F);
     gs4d_obtain(p, *dxyz_hex, P * 4);                  // (dx,dy,dz,dt') per point, normalised coordinates
     gs4d_obtain(p, *dtprime, 3 * ((P + 255) / 256) + 3);   // per-workgroup partial sums for the t' embedding
@@ -1080,7 +1182,7 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     const size_t nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
     int kmax = l.F > l.head_in[0] ? l.F : l.head_in[0];
     for (int h = 0; h < NHEAD; h++) kmax = l.head_in[h] > kmax ? l.head_in[h] : kmax;
-    const size_t pitch = (size_t)((kmax + 1 + 31) / 32) * 32;
+    const size_t pitch = (size_t)((kmax + 12 + 1 + 31) / 32) * 32;     // + the 4-column padding of up to three segments
     *slab_floats_per_job = nchunks * 64 * pitch;
     gs4d_obtain(p, *slabs, *slab_floats_per_job * (2 * NHEAD + GS4D_MAX_TRUNK));
     if (bytes) *bytes = (size_t)(p - base) + 256;
@@ -1257,14 +1359,21 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         rc = launch_gemm(P, jobs, nj, s);
         if (rc) return rc;
     }
-    // trunk backward: dT chain, ending in dfeat
+    // trunk backward: dT chain, ending in dfeat.  Every weight-gradient product of the network (trunk layers,
+    // first and second Linear of each head) is collected into ONE dw_partial / dw_reduce launch pair below.
+    DwJobs dj = {};
+    int ndw = 0, kbmax = 0, nkmax = 0;
+    auto add_dw = [&](const DwJob& q) {
+        kbmax = q.kblocks > kbmax ? q.kblocks : kbmax;
+        nkmax = q.N * (q.K + 1) > nkmax ? q.N * (q.K + 1) : nkmax;
+        dj.j[ndw++] = q;
+    };
     const float* dcur = dZ;  // gradient w.r.t. the output of trunk layer i (columns 0..63)
     int dcur_ld = l.ldz;
-    float* dT_buf[2] = {dT, dT + (size_t)P * WIDTH};
     for (int i = d->trunk_layers - 1; i >= 0; i--) {
         GemmJobs jobs = {};
         const int K = i == 0 ? l.F : WIDTH;
-        float* dst = i == 0 ? dfeat : dT_buf[i & 1];
+        float* dst = i == 0 ? dfeat : dT + (size_t)(i - 1) * P * WIDTH;
         GemmJob& j = jobs.j[0];
         j = simple_job(dcur, dcur_ld, 0, WIDTH, 0, d->trunk_w[i], K, 0, 0, nullptr, K > 64 ? 64 : K, dst, K, 0);
         if (i > 0) { j.mask = w.trunk[i - 1]; j.ldm = WIDTH; j.mcol0 = 0; }
@@ -1276,46 +1385,42 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         }
         rc = launch_gemm(P, jobs, nj, s);
         if (rc) return rc;
-        // NOTE: dcur for the weight gradient of layer i is still needed below, so weight grads are issued per layer
-        {
-            DwJobs dj = {};
-            DwJob& q = dj.j[0];
-            q.G = dcur; q.ldg = dcur_ld; q.gcol0 = 0; q.N = WIDTH;
-            q.X = i == 0 ? w.feat : w.trunk[i - 1]; q.ldx = K; q.x_nseg = 1; q.x_beg[0] = 0; q.x_len[0] = K; q.K = K;
-            q.relu_x = i > 0;
-            q.kblocks = (K + 1 + 31) / 32; q.slabs = slabs + slab_per_job * (2 * NHEAD + i);
-            q.dW = g->trunk_w[i]; q.db = g->trunk_b[i];
-            hipLaunchKernelGGL(dw_partial_kernel, dim3(nchunks, 1, (q.kblocks + 5) / 6), dim3(256), 0, s, P, dj);
-            hipLaunchKernelGGL(dw_reduce_kernel, dim3((WIDTH * (K + 1) + 255) / 256, 1), dim3(256), 0, s, nchunks, dj);
-            GS4D_LAUNCH_CHECK("deform_trunk_dw", 0, s);
-        }
+        DwJob q = {};
+        q.G = dcur; q.ldg = dcur_ld; q.gcol0 = 0; q.N = WIDTH;
+        q.X = i == 0 ? w.feat : w.trunk[i - 1]; q.ldx = K; q.x_nseg = 1; q.x_beg[0] = 0; q.x_len[0] = K; q.K = K;
+        q.relu_x = i > 0;
+        q.Kp = K; q.kblocks = (K + 1 + 31) / 32; q.slabs = slabs + slab_per_job * (2 * NHEAD + i);
+        q.dW = g->trunk_w[i]; q.db = g->trunk_b[i];
+        add_dw(q);
         dcur = dst;
         dcur_ld = K;
     }
-    // head weight gradients (first and second Linear of each head) in one launch pair
+    for (int h = 0; h < NHEAD; h++) {
+        DwJob a = {};
+        a.G = dH1; a.ldg = NHEAD * WIDTH; a.gcol0 = h * WIDTH; a.N = WIDTH;
+        a.X = w.Z; a.ldx = l.ldz; a.x_nseg = 0;
+        a.x_beg[a.x_nseg] = 0; a.x_len[a.x_nseg++] = WIDTH;
+        if (l.head_seglen[h] > 0) { a.x_beg[a.x_nseg] = l.head_seg[h]; a.x_len[a.x_nseg++] = l.head_seglen[h]; }
+        a.x_beg[a.x_nseg] = l.oT; a.x_len[a.x_nseg++] = l.e;
+        a.K = l.head_in[h]; a.relu_x = 1;
+        a.Kp = 0;
+        for (int sg = 0; sg < a.x_nseg; sg++) a.Kp += pad4(a.x_len[sg]);
+        a.kblocks = (a.Kp + 1 + 31) / 32;
+        a.slabs = slabs + slab_per_job * h; a.dW = g->head_w1[h]; a.db = g->head_b1[h];
+        add_dw(a);
+        DwJob b = {};
+        b.G = dO; b.ldg = OUT_LD; b.gcol0 = l.head_ocol[h]; b.N = l.head_out[h];
+        b.X = w.H1; b.ldx = NHEAD * WIDTH; b.x_nseg = 1; b.x_beg[0] = h * WIDTH; b.x_len[0] = WIDTH; b.K = WIDTH;
+        b.relu_x = 1; b.Kp = WIDTH; b.kblocks = (WIDTH + 1 + 31) / 32;
+        b.slabs = slabs + slab_per_job * (NHEAD + h); b.dW = g->head_w2[h]; b.db = g->head_b2[h];
+        add_dw(b);
+    }
     {
-        DwJobs dj = {};
-        int kbmax = 0, nkmax = 0;
-        for (int h = 0; h < NHEAD; h++) {
-            DwJob& a = dj.j[h];
-            a.G = dH1; a.ldg = NHEAD * WIDTH; a.gcol0 = h * WIDTH; a.N = WIDTH;
-            a.X = w.Z; a.ldx = l.ldz; a.x_nseg = 0;
-            a.x_beg[a.x_nseg] = 0; a.x_len[a.x_nseg++] = WIDTH;
-            if (l.head_seglen[h] > 0) { a.x_beg[a.x_nseg] = l.head_seg[h]; a.x_len[a.x_nseg++] = l.head_seglen[h]; }
-            a.x_beg[a.x_nseg] = l.oT; a.x_len[a.x_nseg++] = l.e;
-            a.K = l.head_in[h]; a.relu_x = 1; a.kblocks = (a.K + 1 + 31) / 32;
-            a.slabs = slabs + slab_per_job * h; a.dW = g->head_w1[h]; a.db = g->head_b1[h];
-            DwJob& b = dj.j[NHEAD + h];
-            b.G = dO; b.ldg = OUT_LD; b.gcol0 = l.head_ocol[h]; b.N = l.head_out[h];
-            b.X = w.H1; b.ldx = NHEAD * WIDTH; b.x_nseg = 1; b.x_beg[0] = h * WIDTH; b.x_len[0] = WIDTH; b.K = WIDTH;
-            b.relu_x = 1; b.kblocks = (WIDTH + 1 + 31) / 32;
-            b.slabs = slabs + slab_per_job * (NHEAD + h); b.dW = g->head_w2[h]; b.db = g->head_b2[h];
-            kbmax = a.kblocks > kbmax ? a.kblocks : kbmax;
-            nkmax = WIDTH * (a.K + 1) > nkmax ? WIDTH * (a.K + 1) : nkmax;
-        }
-        hipLaunchKernelGGL(dw_partial_kernel, dim3(nchunks, 2 * NHEAD, (kbmax + 5) / 6), dim3(256), 0, s, P, dj);
-        hipLaunchKernelGGL(dw_reduce_kernel, dim3((nkmax + 255) / 256, 2 * NHEAD), dim3(256), 0, s, nchunks, dj);
-        GS4D_LAUNCH_CHECK("deform_head_dw", 0, s);
+        dj.njobs = ndw; dj.nz = (kbmax + 5) / 6; dj.nchunks = nchunks;
+        const int grid = (nchunks + 7) / 8 * 8 * ndw * dj.nz;
+        hipLaunchKernelGGL(dw_partial_kernel, dim3(grid), dim3(256), 0, s, P, dj);
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3((nkmax + 63) / 64, ndw), dim3(256), 0, s, nchunks, dj);
+        GS4D_LAUNCH_CHECK("deform_dw", 0, s);
     }
     // PE tails -> inputs (accumulates onto the pass-through gradients written by outputs_backward)
     PeArgs pa = {P, l.ldz, l.oX, l.oS, l.oR, l.oT, l.oF, l.Kz, d->pos_pe, d->sr_pe, d->time_pe, d->force_pe,
