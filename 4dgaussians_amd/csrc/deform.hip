@@ -758,6 +758,8 @@ struct DwJobs { DwJob j[16]; int njobs, nz, nchunks; };
 // disjoint banks).  The earlier version fetched operands per wave straight from global memory: every G block
 // was read by two waves and every X block by two more, 1.8 GB of L2 traffic per step for 0.4 GB of data.
 #define DW_RB 16
+#define DW_NG (DW_RB / 16)       // float4s of G per thread and sub-block
+#define DW_NX (3 * DW_RB / 16)   // float4s of X
 #define DW_GP 96
 #define DW_XP 224
 #define DW_XCOLS 192
@@ -784,8 +786,9 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     const int l31 = lane & 31, half = lane >> 5;
     const int nn = (J.N + 31) >> 5;                         // 1 or 2 n-blocks
     const int ntiles = nn * nkb;                            // <= 12; wave w owns tiles w, w+4, w+8 (all with n-block w % nn)
-    const int cnt = (ntiles - wave + 3) >> 2;
-    const int nb = wave % nn;
+    const int vw = (wave + chunk) & 3;                      // rotate the tile deal so the 3-tile waves do not all sit on one SIMD
+    const int cnt = (ntiles - vw + 3) >> 2;
+    const int nb = vw % nn;
     const int rbeg = chunk * DW_ROWS_PER_WG, rend = min(P, rbeg + DW_ROWS_PER_WG);
 
     // staged 4-column group -> source column of X.  Segments begin on 4-float boundaries and every segment but
@@ -804,10 +807,10 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     }
     __syncthreads();
     // fixed staging assignments of this thread: one float4 of G (16 rows x 16 groups), three of X (16 x 48)
-    int xoff[3], xrow[3], xdst[3], xk[3];
-    bool xlive[3];
+    int xoff[DW_NX], xrow[DW_NX], xdst[DW_NX], xk[DW_NX];
+    bool xlive[DW_NX];
 #pragma unroll
-    for (int i = 0; i < 3; i++) {
+    for (int i = 0; i < DW_NX; i++) {
         const int e = tid + 256 * i;
         const int row = e / (DW_XCOLS / 4), grp = e - row * (DW_XCOLS / 4);
         xrow[i] = row;
@@ -822,22 +825,27 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     const int ldg = J.ldg, ldx = J.ldx, N = J.N, K = J.Kp;
     const bool relu = J.relu_x != 0;
 
-    float4 gv, xv[3];
-    auto fetch = [&](int r0) {
-        gv = *reinterpret_cast<const float4*>(Gp + (size_t)min(r0 + grow, rend - 1) * ldg);
+    float4 gvs[2][DW_NG], xvs[2][DW_NX];     // two register sets: loads run two sub-blocks ahead of the MFMAs
+    auto fetch = [&](float4 (&gv)[DW_NG], float4 (&xv)[DW_NX], int r0) {
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+        for (int i = 0; i < DW_NG; i++)
+            gv[i] = *reinterpret_cast<const float4*>(Gp + (size_t)min(r0 + grow + 16 * i, rend - 1) * ldg);
+#pragma unroll
+        for (int i = 0; i < DW_NX; i++)
             if (xlive[i] && xoff[i] >= 0)
                 xv[i] = *reinterpret_cast<const float4*>(Xp + (size_t)min(r0 + xrow[i], rend - 1) * ldx + xoff[i]);
     };
-    auto stash = [&](int r0, int buf) {
-        const bool rok = r0 + grow < rend;
-        float g4[4] = {gv.x, gv.y, gv.z, gv.w};
+    auto stash = [&](const float4 (&gv)[DW_NG], const float4 (&xv)[DW_NX], int r0, int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) g4[q] = (rok && 4 * ggrp + q < N) ? g4[q] : 0.f;
-        *reinterpret_cast<float4*>(&sG[buf][grow * DW_GP + 4 * ggrp]) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        for (int i = 0; i < DW_NG; i++) {
+            const bool rok = r0 + grow + 16 * i < rend;
+            float g4[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
 #pragma unroll
-        for (int i = 0; i < 3; i++) {
+            for (int q = 0; q < 4; q++) g4[q] = (rok && 4 * ggrp + q < N) ? g4[q] : 0.f;
+            *reinterpret_cast<float4*>(&sG[buf][(grow + 16 * i) * DW_GP + 4 * ggrp]) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < DW_NX; i++) {
             if (!xlive[i]) continue;
             float x4[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
 #pragma unroll
@@ -851,41 +859,48 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     };
 
     f32x16 acc[3] = {{0}, {0}, {0}};
-    fetch(rbeg);
-    stash(rbeg, 0);
+    fetch(gvs[0], xvs[0], rbeg);
+    if (rbeg + DW_RB < rend) fetch(gvs[1], xvs[1], rbeg + DW_RB);
+    stash(gvs[0], xvs[0], rbeg, 0);
     __syncthreads();
-    int buf = 0;
-    for (int r = rbeg; r < rend; r += DW_RB, buf ^= 1) {
-        const bool more = r + DW_RB < rend;
-        if (more) fetch(r + DW_RB);
-        if (cnt > 0) {
-            const float* ga = &sG[buf][half * DW_GP + nb * 32 + l31];
-            const float* xb = &sX[buf][half * DW_XP + (wave / nn) * 32 + l31];
-            const int kstep = (4 / nn) * 32;                // k-block distance between the wave's consecutive tiles
+    if (rbeg + 2 * DW_RB < rend) fetch(gvs[0], xvs[0], rbeg + 2 * DW_RB);
+    const float* ga0 = &sG[0][half * DW_GP + nb * 32 + l31];
+    const float* xb0 = &sX[0][half * DW_XP + (vw / nn) * 32 + l31];
+    const int kstep = (4 / nn) * 32;                        // k-block distance between the wave's consecutive tiles
+    for (int r = rbeg; r < rend; r += 2 * DW_RB) {
 #pragma unroll
-            for (int st = 0; st < DW_RB / 2; st++) {
-                const float a = ga[2 * st * DW_GP];
-                const float b0 = xb[2 * st * DW_XP];
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                if (cnt > 1) {
-                    const float b1 = xb[2 * st * DW_XP + kstep];
-                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-                }
-                if (cnt > 2) {
-                    const float b2 = xb[2 * st * DW_XP + 2 * kstep];
-                    acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+        for (int u = 0; u < 2; u++) {
+            const int rr = r + u * DW_RB;
+            if (rr >= rend) break;                          // uniform
+            if (cnt > 0) {
+                const float* ga = ga0 + u * (DW_RB * DW_GP);
+                const float* xb = xb0 + u * (DW_RB * DW_XP);
+#pragma unroll
+                for (int st = 0; st < DW_RB / 2; st++) {
+                    const float a = ga[2 * st * DW_GP];
+                    const float b0 = xb[2 * st * DW_XP];
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
+                    if (cnt > 1) {
+                        const float b1 = xb[2 * st * DW_XP + kstep];
+                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+                    }
+                    if (cnt > 2) {
+                        const float b2 = xb[2 * st * DW_XP + 2 * kstep];
+                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
+                    }
                 }
             }
+            if (rr + DW_RB < rend) stash(gvs[u ^ 1], xvs[u ^ 1], rr + DW_RB, u ^ 1);
+            if (rr + 3 * DW_RB < rend) fetch(gvs[u ^ 1], xvs[u ^ 1], rr + 3 * DW_RB);
+            __syncthreads();
         }
-        if (more) stash(r + DW_RB, buf ^ 1);
-        __syncthreads();
     }
     const int pitch = 32 * J.kblocks;
     float* slab = J.slabs + (size_t)chunk * 64 * pitch;
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         if (t >= cnt) continue;
-        const int kb = kb_first + wave / nn + t * (4 / nn);
+        const int kb = kb_first + vw / nn + t * (4 / nn);
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
