@@ -37,7 +37,6 @@
 #define ROWS_PER_WG 128
 #define GEMM_CUS 256
 #define DW_ROWS_PER_WG 512
-#define STRIP_WGS 256           // point runs of the time-plane strip kernel (x3 planes)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -224,23 +223,58 @@ __device__ __forceinline__ SixSamples six_samples(const PlaneTable& T, int l, in
     return o;
 }
 
-__device__ __constant__ const int kSpatial[3] = {0, 1, 3};
-__device__ __constant__ const int kTimeP[3] = {2, 4, 5};
+// ---- plane gradients: bin, then reduce in cell order -------------------------------------------------
+// Memory-side float atomics run at one chip-wide rate (~1.2 TB/s measured), and the direct scatter issues
+// 4 corner rows per (point, plane, level): 4.8 M rows of 128 B at C2 = 250 us for the spatial planes alone.
+// Neighbouring points share texels, so the adds are combined BEFORE they reach memory:
+//   1. hexplane_backward_point_kernel (per point, no atomics on floats) writes gsix[p][l][plane][ch] =
+//      dL/d(sample of that plane) and the coordinate gradients, and ranks the point inside its finest-level
+//      cell of three "sort planes" (one int atomic each);
+//   2. a counting sort per sort plane orders the points by cell: xy A-major (also groups the xt plane by x),
+//      yz A-major (groups yt by y), xz B-major (groups zt by z);
+//   3. hexplane_backward_reduce_kernel walks fixed runs of RUN consecutive sorted points per (plane, level),
+//      accumulates the four corner sums of the current cell in registers and flushes them with four atomic
+//      rows only when the cell changes: ~6x (fine level) to ~25x (coarse level, time planes) fewer atomic
+//      rows.  Correctness never depends on the grouping (a flush happens on every cell change), so per-point
+//      timestamps, clustered scenes and non-power-of-two multires just change how often it flushes.
+#define HEX_SORTS 3
+#define HEX_RUN 32
+#define HEX_MAX_BINS 65536
+struct HexBins {
+    int plane[HEX_SORTS];      // finest-level plane whose cells order sort s: xy, yz, xz
+    int bmajor[HEX_SORTS];     // 1: key = y0 * W + x0 (B-major), 0: key = x0 * H + y0
+    int shift[HEX_SORTS];      // cells are coarsened by this many bits if the plane has more than HEX_MAX_BINS cells
+    int nbins;                 // bins per sort (max over the sorts)
+};
+// plane i of a level is served by sort kSortOf[i]; its (A, B) coordinates are fields kSelA/kSelB of the sorted
+// record (p, a, b, t'): S0 = (x, y), S1 = (y, z), S2 = (x, z)
+__device__ __constant__ const int kSortOf[6] = {0, 2, 0, 1, 1, 2};
+__device__ __constant__ const int kSelA[6] = {0, 0, 0, 0, 0, 1};
+__device__ __constant__ const int kSelB[6] = {1, 1, 2, 1, 2, 2};
 
-// Backward, spatial planes (xy, xz, yz) and the coordinate gradients: one lane per channel (C lanes per
-// point, C <= 64; for C > 64 a lane loops), so each atomic wave-instruction covers whole contiguous
-// channel rows (128-B segments: the full-rate shape for memory-side float atomics).
-__global__ __launch_bounds__(256) void hexplane_backward_spatial_kernel(
-    int P, int C, int L, int lanes_shift, PlaneTable T, const float* __restrict__ aabb,
+__device__ __forceinline__ int hex_key(const HexBins& B, int s, int x0, int y0, int Ww, int Hh)
+{
+    const int sh = B.shift[s];
+    const int xs = x0 >> sh, ys = y0 >> sh;
+    const int ws = ((Ww - 1) >> sh) + 1, hs = ((Hh - 1) >> sh) + 1;
+    return B.bmajor[s] ? ys * ws + xs : xs * hs + ys;
+}
+
+// C/4 lanes per point, four channels (one float4 per corner) per lane, as in the forward gather.
+__global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
+    int P, int C, int L, int lpp_shift, PlaneTable T, HexBins B, const float* __restrict__ aabb,
     const float* __restrict__ xyz, const float* __restrict__ tprime, const float* __restrict__ dfeat, int ldf,
     float4* __restrict__ dcoord,               // [P]: (d/dx, d/dy, d/dz, d/dt') in normalised coordinates
-    float* __restrict__ gtime)                 // [P][L][3][C]: dL/d(sample) of the three time planes, for the strip kernel
+    float* __restrict__ gsix,                  // [P][L][6][C]: dL/d(sample) of every plane
+    int* __restrict__ hist,                    // [HEX_SORTS][nbins], zeroed by the caller
+    int* __restrict__ rank, int* __restrict__ key)   // [HEX_SORTS][P]
 {
-    const int lanes = 1 << lanes_shift;                 // lanes per point = min(C, 64)
+    const int lanes = 1 << lpp_shift;
     const int gtid = blockIdx.x * 256 + threadIdx.x;
-    const int p = gtid >> lanes_shift;
+    const int p = gtid >> lpp_shift;
     const int sub = gtid & (lanes - 1);
     const bool live = p < P;
+    const int q4 = C >> 2;
     float pts[4] = {0.f, 0.f, 0.f, 0.f};
     if (live) {
 #pragma unroll
@@ -251,202 +285,238 @@ __global__ __launch_bounds__(256) void hexplane_backward_spatial_kernel(
         pts[3] = tprime[p];
     }
     float dpts[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int l = 0; l < L; l++) {
-        Corner cn[6];
+    if (live && sub == 0) {                     // rank the point inside its finest-level cell of every sort plane
 #pragma unroll
-        for (int i = 0; i < 6; i++) cn[i] = corner_of(pts[kPairA[i]], pts[kPairB[i]], T.w[l * 6 + i], T.h[l * 6 + i]);
-        for (int ch = sub; ch < C; ch += lanes) {
-            if (!live) continue;
-            const SixSamples q = six_samples(T, l, C, ch, cn, dfeat[(size_t)p * ldf + l * C + ch]);
+        for (int s = 0; s < HEX_SORTS; s++) {
+            const int i = B.plane[s], pl = (L - 1) * 6 + i;
+            float u = 0.f, v = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const int i = kSpatial[j];
-                float* __restrict__ gb = T.g[l * 6 + i] + ch;
-                unsafeAtomicAdd(gb + (size_t)cn[i].i00 * C, q.gi[i] * cn[i].w00);
-                unsafeAtomicAdd(gb + (size_t)cn[i].i01 * C, q.gi[i] * cn[i].w01);
-                unsafeAtomicAdd(gb + (size_t)cn[i].i10 * C, q.gi[i] * cn[i].w10);
-                unsafeAtomicAdd(gb + (size_t)cn[i].i11 * C, q.gi[i] * cn[i].w11);
-                gtime[(((size_t)p * L + l) * 3 + j) * C + ch] = q.gi[kTimeP[j]];
-            }
+            for (int k = 0; k < 6; k++)
+                if (k == i) { u = pts[kPairA[k]]; v = pts[kPairB[k]]; }
+            const Corner c = corner_of(u, v, T.w[pl], T.h[pl]);
+            const int k = hex_key(B, s, c.x0, c.y0, T.w[pl], T.h[pl]);
+            key[(size_t)s * P + p] = k;
+            rank[(size_t)s * P + p] = atomicAdd(&hist[s * B.nbins + k], 1);
+        }
+    }
+    if (live) {
+        for (int l = 0; l < L; l++) {
+            float4 v[6], dx[6], dy[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                dpts[kPairA[i]] += q.gi[i] * q.ddx[i];
-                dpts[kPairB[i]] += q.gi[i] * q.ddy[i];
+                const int pl = l * 6 + i;
+                const Corner c = corner_of(pts[kPairA[i]], pts[kPairB[i]], T.w[pl], T.h[pl]);
+                const float4* __restrict__ base = reinterpret_cast<const float4*>(T.p[pl]) + sub;
+                const float4 f00 = base[(size_t)c.i00 * q4], f01 = base[(size_t)c.i01 * q4];
+                const float4 f10 = base[(size_t)c.i10 * q4], f11 = base[(size_t)c.i11 * q4];
+                const float ax = (1.f - c.wy) * c.sx, bx = c.wy * c.sx, ay = (1.f - c.wx) * c.sy, by = c.wx * c.sy;
+#define HEX_COMP(m)                                                                                   \
+                v[i].m = f00.m * c.w00 + f01.m * c.w01 + f10.m * c.w10 + f11.m * c.w11;               \
+                dx[i].m = (f01.m - f00.m) * ax + (f11.m - f10.m) * bx;                                 \
+                dy[i].m = (f10.m - f00.m) * ay + (f11.m - f01.m) * by;
+                HEX_COMP(x) HEX_COMP(y) HEX_COMP(z) HEX_COMP(w)
+#undef HEX_COMP
+            }
+            const float4 g = *reinterpret_cast<const float4*>(dfeat + (size_t)p * ldf + l * C + 4 * sub);
+            // product of the other five planes via prefix / suffix products (no division)
+            float4 pre[6], suf[6];
+            pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+            suf[5] = pre[0];
+#pragma unroll
+            for (int i = 1; i < 6; i++) pre[i] = make_float4(pre[i - 1].x * v[i - 1].x, pre[i - 1].y * v[i - 1].y, pre[i - 1].z * v[i - 1].z, pre[i - 1].w * v[i - 1].w);
+#pragma unroll
+            for (int i = 4; i >= 0; i--) suf[i] = make_float4(suf[i + 1].x * v[i + 1].x, suf[i + 1].y * v[i + 1].y, suf[i + 1].z * v[i + 1].z, suf[i + 1].w * v[i + 1].w);
+            float4* __restrict__ out = reinterpret_cast<float4*>(gsix + ((size_t)p * L + l) * 6 * C) + sub;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const float4 gi = make_float4(g.x * pre[i].x * suf[i].x, g.y * pre[i].y * suf[i].y, g.z * pre[i].z * suf[i].z, g.w * pre[i].w * suf[i].w);
+                out[(size_t)i * q4] = gi;
+                dpts[kPairA[i]] += (gi.x * dx[i].x + gi.y * dx[i].y) + (gi.z * dx[i].z + gi.w * dx[i].w);
+                dpts[kPairB[i]] += (gi.x * dy[i].x + gi.y * dy[i].y) + (gi.z * dy[i].z + gi.w * dy[i].w);
             }
         }
     }
-    // sum the per-channel coordinate gradients over the point's lanes
 #pragma unroll
     for (int a = 0; a < 4; a++)
         for (int off = lanes >> 1; off >= 1; off >>= 1) dpts[a] += __shfl_xor(dpts[a], off, 64);
     if (live && sub == 0) dcoord[p] = make_float4(dpts[0], dpts[1], dpts[2], dpts[3]);
 }
 
-// Backward, time planes (xt, yt, zt).  All Gaussians of a view share one timestamp, so their time-plane
-// gradients land in just two texel rows per plane; adding them with memory-side atomics means ~P*4 adds
-// per plane contending for a few hundred rows (an order of magnitude below the atomic rate), and LDS
-// float atomics (ds_add_f32) measured ~0.3 lanes/clk here.  Instead the two rows are computed as a small
-// dense product on the f32 matrix cores:
-//     strip[r][x][ch] = sum_p  Wgt_r[x][p] * G[p][ch],   Wgt_r[x][p] = bilinear weight of point p at (row r, column x)
-// with K = the points of the wave's run (two per v_mfma_f32_32x32x2_f32), one 32-column bucket of x per
-// accumulator tile.  The A operand is built in registers from the point's corner (4 non-zeros per point), the
-// B operand is the point's gradient row written by the spatial kernel: no LDS, no atomics, no sorting inside
-// the loop, and a fixed summation order.  The four waves of a workgroup are summed through LDS, the
-// workgroups by hexplane_strip_reduce_kernel.  A point whose time rows differ from the run's (per-point
-// timestamps) takes the global-atomic path, so correctness does not depend on the shared timestamp.
-struct StripPlan {
-    int off[GS4D_MAX_LEVELS];     // float offset of the level's strip ([2][W][C]) in a workgroup's partial record
-    int points_per_wg;
-};
-
-#define TIME_BUCKETS 4      // 32-column buckets per pass: 8 accumulator tiles (128 registers)
-#define TIME_UNROLL 4       // MFMA k-steps (point pairs) whose loads are in flight together
-__global__ __launch_bounds__(256, 2) void hexplane_backward_time_kernel(
-    int P, int C, int L, PlaneTable T, StripPlan plan, const float* __restrict__ aabb,
-    const float* __restrict__ xyz, const float* __restrict__ tprime, const float* __restrict__ gtime,
-    float* __restrict__ strip_part, int* __restrict__ strip_rows, int strip_total)
+// exclusive prefix sum of each sort's histogram, in place; one workgroup of 1024 lanes per sort
+__global__ __launch_bounds__(1024) void hexplane_bin_scan_kernel(int nbins, int* __restrict__ hist)
 {
-    __shared__ float red[2 * 32 * TIME_BUCKETS * 32];    // [row][column of the pass][channel of the block]
-    __shared__ int s_row0[GS4D_MAX_LEVELS], s_row1[GS4D_MAX_LEVELS];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int khalf = lane >> 5, col = lane & 31;
-    const int j = blockIdx.y;
-    const int itp = kTimeP[j];
-    const int axis = kPairA[itp];                       // the plane's spatial axis
-    const int pbeg = blockIdx.x * plan.points_per_wg, pend = min(P, pbeg + plan.points_per_wg);   // host: never empty
-    const int per_wave = ((pend - pbeg + 3) / 4 + 1) & ~1;                                      // even
-    const int wbeg = min(pend, pbeg + wave * per_wave), wend = min(pend, wbeg + per_wave);
-    const size_t slot = (size_t)blockIdx.x * 3 + j;
-    float* __restrict__ out = strip_part + slot * strip_total;
-
-    if (tid < L) {     // strip rows of this run: the time rows of its first point
-        const Corner c = corner_of(0.f, tprime[pbeg], T.w[tid * 6 + itp], T.h[tid * 6 + itp]);
-        s_row0[tid] = c.y0;
-        s_row1[tid] = c.y1;
-        strip_rows[(slot * GS4D_MAX_LEVELS + tid) * 2 + 0] = c.y0;
-        strip_rows[(slot * GS4D_MAX_LEVELS + tid) * 2 + 1] = c.y1;
+    __shared__ int part[16];
+    int* h = hist + (size_t)blockIdx.x * nbins;
+    // lane t owns bins t, t + 1024, ... of every 1024-bin stripe?  No: contiguous bins per lane keep the scan a
+    // plain running sum; the HEX_MAX_BINS / 1024 = 64 loads of a lane are independent and issued together.
+    const int per = (nbins + 1023) / 1024;                  // <= 64
+    const int b0 = threadIdx.x * per;
+    int v[HEX_MAX_BINS / 1024];
+#pragma unroll
+    for (int k = 0; k < HEX_MAX_BINS / 1024; k++) v[k] = (k < per && b0 + k < nbins) ? h[b0 + k] : 0;
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < HEX_MAX_BINS / 1024; k++) s += v[k];
+    // inclusive scan of the lane sums: inside the wave by shuffles, across the 16 waves through LDS
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int u = __shfl_up(inc, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) inc += u;
     }
+    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = inc;
     __syncthreads();
-
-    const float lo = aabb[axis], hi = aabb[3 + axis];
-    for (int l = 0; l < L; l++) {
-        const int Wt = T.w[l * 6 + itp], Ht = T.h[l * 6 + itp];
-        const int row0 = s_row0[l], row1 = s_row1[l];
-        float* __restrict__ gplane = T.g[l * 6 + itp];
-        const int nbuckets = (Wt + 31) / 32;
-        for (int cb = 0; cb * 32 < C; cb++) {
-            const int ch = cb * 32 + col;
-            const bool chok = ch < C;
-            for (int b0 = 0; b0 < nbuckets; b0 += TIME_BUCKETS) {
-                f32x16 acc[2 * TIME_BUCKETS];
+    int wave_prefix = 0;
+    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wave_prefix += part[w];
+    int run = wave_prefix + inc - s;
 #pragma unroll
-                for (int t = 0; t < 2 * TIME_BUCKETS; t++) acc[t] = (f32x16){0};
-                for (int p0 = wbeg; p0 < wend; p0 += 2 * TIME_UNROLL) {
-                    float u[TIME_UNROLL], tt[TIME_UNROLL], g[TIME_UNROLL];
-#pragma unroll
-                    for (int k = 0; k < TIME_UNROLL; k++) {
-                        const int p = min(p0 + 2 * k + khalf, pend - 1);
-                        u[k] = xyz[3 * (size_t)p + axis];
-                        tt[k] = tprime[p];
-                        g[k] = gtime[(((size_t)p * L + l) * 3 + j) * C + min(ch, C - 1)];
-                    }
-#pragma unroll
-                    for (int k = 0; k < TIME_UNROLL; k++) {
-                        const bool ok = p0 + 2 * k + khalf < wend;
-                        const Corner c = corner_of((u[k] - lo) * (2.0f / (hi - lo)) - 1.0f, tt[k], Wt, Ht);
-                        const bool in_strip = c.y0 == row0 && c.y1 == row1;
-                        float gk = (ok && chok) ? g[k] : 0.f;
-                        if (!in_strip) {                 // rare: per-point timestamps
-                            if (gk != 0.f && b0 == 0) {
-                                float* __restrict__ gb = gplane + ch;
-                                unsafeAtomicAdd(gb + (size_t)c.i00 * C, gk * c.w00);
-                                unsafeAtomicAdd(gb + (size_t)c.i01 * C, gk * c.w01);
-                                unsafeAtomicAdd(gb + (size_t)c.i10 * C, gk * c.w10);
-                                unsafeAtomicAdd(gb + (size_t)c.i11 * C, gk * c.w11);
-                            }
-                            gk = 0.f;
-                        }
-                        const bool merged = c.x1 == c.x0;   // right border: one texel (the weight of x1 is 0 there)
-#pragma unroll
-                        for (int bb = 0; bb < TIME_BUCKETS; bb++) {
-                            if (32 * (b0 + bb) >= Wt) break;          // narrower plane: fewer buckets (uniform)
-                            const int xg = 32 * (b0 + bb) + col;      // this lane's row of the A operand
-                            const bool m0 = c.x0 == xg, m1 = !merged && c.x1 == xg;
-                            const float a0 = (m0 ? (merged ? c.w00 + c.w01 : c.w00) : 0.f) + (m1 ? c.w01 : 0.f);
-                            const float a1 = (m0 ? (merged ? c.w10 + c.w11 : c.w10) : 0.f) + (m1 ? c.w11 : 0.f);
-                            acc[2 * bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, gk, acc[2 * bb], 0, 0, 0);
-                            acc[2 * bb + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, gk, acc[2 * bb + 1], 0, 0, 0);
-                        }
-                    }
-                }
-                // sum the four waves in wave order through LDS
-                for (int w = 0; w < 4; w++) {
-                    if (wave == w) {
-#pragma unroll
-                        for (int t = 0; t < 2 * TIME_BUCKETS; t++) {
-#pragma unroll
-                            for (int q = 0; q < 16; q++) {
-                                const int xl = 32 * (t >> 1) + (q & 3) + 8 * (q >> 2) + 4 * khalf;   // column inside the pass
-                                float* dst = red + (((t & 1) * 32 * TIME_BUCKETS + xl) * 32 + col);
-                                if (w == 0) *dst = acc[t][q];
-                                else *dst += acc[t][q];
-                            }
-                        }
-                    }
-                    __syncthreads();
-                }
-                // this pass's columns of the workgroup's partial record
-                const int ncols = min(32 * TIME_BUCKETS, Wt - 32 * b0);
-                for (int i = tid; i < 2 * ncols * 32; i += 256) {
-                    const int c2 = i & 31, xl = (i >> 5) % ncols, r = (i >> 5) / ncols;
-                    if (cb * 32 + c2 < C)
-                        out[plan.off[l] + ((size_t)r * Wt + 32 * b0 + xl) * C + cb * 32 + c2] = red[((r * 32 * TIME_BUCKETS + xl) * 32) + c2];
-                }
-                __syncthreads();
-            }
-        }
+    for (int k = 0; k < HEX_MAX_BINS / 1024; k++) {
+        if (k < per && b0 + k < nbins) h[b0 + k] = run;
+        run += v[k];
     }
 }
 
-// Sums the workgroups' strips in workgroup order and adds each run of equal target rows to the plane
-// gradient (one atomic per element when every point shares the timestamp; the atomic only matters when
-// two strip rows of different runs alias the same texel row).
-__global__ __launch_bounds__(256) void hexplane_strip_reduce_kernel(int nwg, int C, int L, PlaneTable T, StripPlan plan,
-                                                                    const float* __restrict__ strip_part,
-                                                                    const int* __restrict__ strip_rows, int strip_total)
+// sorted record of sort s at position start[key] + rank: (p, a, b, t') with (a, b) = (x,y), (y,z), (x,z)
+__global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int nbins, const float* __restrict__ aabb,
+                                                                   const float* __restrict__ xyz,
+                                                                   const float* __restrict__ tprime,
+                                                                   const int* __restrict__ start,
+                                                                   const int* __restrict__ rank,
+                                                                   const int* __restrict__ key, float4* __restrict__ rec)
 {
-    const int j = blockIdx.y, itp = kTimeP[j];
-    const int e = blockIdx.x * 256 + threadIdx.x;       // element of the concatenated strips
-    if (e >= strip_total) return;
-    int l = -1;
-    for (int k = 0; k < L; k++)
-        if (plan.off[k] >= 0 && e >= plan.off[k] && e < plan.off[k] + 2 * T.w[k * 6 + itp] * C) l = k;
-    if (l < 0) return;
-    const int n = T.w[l * 6 + itp] * C;
-    const int r = (e - plan.off[l]) / n, i = (e - plan.off[l]) % n;
-    float* __restrict__ g = T.g[l * 6 + itp];
-    float acc = 0.f;
-    int cur = -1;
-    for (int w0 = 0; w0 < nwg; w0 += 8) {
-        int row[8]; float v[8];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= P) return;
+    float pts[3];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {      // eight independent loads in flight
-            const size_t slot = (size_t)min(w0 + k, nwg - 1) * 3 + j;
-            row[k] = strip_rows[(slot * GS4D_MAX_LEVELS + l) * 2 + r];
-            v[k] = strip_part[slot * strip_total + e];
+    for (int a = 0; a < 3; a++) {
+        const float lo = aabb[a], hi = aabb[3 + a];
+        pts[a] = (xyz[3 * (size_t)p + a] - lo) * (2.0f / (hi - lo)) - 1.0f;
+    }
+    const float t = tprime[p];
+    const float ra[HEX_SORTS] = {pts[0], pts[1], pts[0]}, rb[HEX_SORTS] = {pts[1], pts[2], pts[2]};
+#pragma unroll
+    for (int s = 0; s < HEX_SORTS; s++) {
+        const int pos = start[s * nbins + key[(size_t)s * P + p]] + rank[(size_t)s * P + p];
+        rec[(size_t)s * P + pos] = make_float4(__int_as_float(p), ra[s], rb[s], t);
+    }
+}
+
+// blockIdx.y = level * 6 + plane.  min(C, 64) lanes (one per channel) walk runs of HEX_RUN sorted points; a
+// workgroup owns HEX_RPW * (256 / lanes) consecutive runs.  Per HEX_RPW step the corners of the step's entries
+// are computed once (one lane per entry) into LDS; the gradient rows are gathered eight entries at a time.
+// Same-line memory-side atomics serialise at ~0.5 us each (measured: the 128 hot texel rows of a coarse time
+// plane cost 57 us when every run flushed to memory), so the time planes -- whose points all sit in the same
+// two texel rows -- flush into a small LDS tile [HEX_TCOL columns][2 rows] anchored at the workgroup's first
+// entry and the tile goes to memory once per workgroup; anything outside the tile (other rows: per-point
+// timestamps; farther columns: sparse regions) takes the direct atomic.
+#define HEX_GATHER 8
+#define HEX_RPW 4
+#define HEX_TCOL 16
+__global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, int C, int L, int lanes_shift, PlaneTable T,
+                                                                       const float4* __restrict__ rec,
+                                                                       const float* __restrict__ gsix)
+{
+    extern __shared__ float4 s_mem[];                       // corner weights | corner indices | tile
+    const int lanes = 1 << lanes_shift;
+    const int pl = blockIdx.y, l = pl / 6, i = pl % 6;
+    const bool is_time = i == 2 || i == 4 || i == 5;
+    const int runs_wg = 256 >> lanes_shift;
+    const int step_entries = runs_wg * HEX_RUN;
+    const int lrun = threadIdx.x >> lanes_shift;
+    const int sub = threadIdx.x & (lanes - 1);
+    const float4* __restrict__ R = rec + (size_t)kSortOf[i] * P;
+    const size_t wg_e0 = (size_t)blockIdx.x * step_entries * HEX_RPW;
+    if (wg_e0 >= (size_t)P) return;                         // uniform
+    const int Ww = T.w[pl], Hh = T.h[pl];
+    const int selA = kSelA[i], selB = kSelB[i];
+    float4* s_w = s_mem;
+    int4* s_i = reinterpret_cast<int4*>(s_mem + step_entries);
+    float* tile = reinterpret_cast<float*>(s_mem + 2 * step_entries);     // [HEX_TCOL][2][lanes]
+    int xbase, ybase;
+    {
+        const float4 r = R[wg_e0];
+        const float f[3] = {r.y, r.z, r.w};
+        const Corner c = corner_of(f[selA], f[selB], Ww, Hh);
+        xbase = c.x0; ybase = c.y0;
+    }
+    float* __restrict__ G = T.g[pl];
+    const float* __restrict__ gbase = gsix + ((size_t)l * 6 + i) * C;
+    const size_t pstride = (size_t)L * 6 * C;
+    for (int ch0 = 0; ch0 < C; ch0 += lanes) {
+        const int ch = ch0 + sub;
+        if (is_time) {
+            for (int k = threadIdx.x; k < HEX_TCOL * 2 * lanes; k += 256) tile[k] = 0.f;
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (w0 + k >= nwg) break;
-            if (row[k] != cur) {
-                if (cur >= 0 && acc != 0.f) unsafeAtomicAdd(g + (size_t)cur * n + i, acc);
-                acc = 0.f;
-                cur = row[k];
+        for (int it = 0; it < HEX_RPW; it++) {
+            const size_t st_e0 = wg_e0 + (size_t)it * step_entries;
+            __syncthreads();                                // previous step's readers are done (and the tile is zeroed)
+            if (st_e0 >= (size_t)P) break;                  // uniform
+            // the corner of an entry is the same for every channel: computed once per entry, by one lane
+            for (int k = threadIdx.x; k < step_entries; k += 256) {
+                if (st_e0 + k >= (size_t)P) break;
+                const float4 r = R[st_e0 + k];
+                const float f[3] = {r.y, r.z, r.w};
+                const Corner c = corner_of(f[selA], f[selB], Ww, Hh);
+                s_w[k] = make_float4(c.w00, c.w01, c.w10, c.w11);
+                s_i[k] = make_int4(__float_as_int(r.x), c.x0 | (c.y0 << 16), c.x1 - c.x0, c.y1 - c.y0);
             }
-            acc += v[k];
+            __syncthreads();
+            const size_t e0 = st_e0 + (size_t)lrun * HEX_RUN;
+            if (e0 >= (size_t)P) continue;
+            const int n = (int)min((size_t)HEX_RUN, (size_t)P - e0);
+            const float4* __restrict__ myw = s_w + lrun * HEX_RUN;
+            const int4* __restrict__ myi = s_i + lrun * HEX_RUN;
+            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+            int cell = -1, dx = 0, dy = 0;
+            auto flush = [&]() {
+                const int x0 = cell & 0xFFFF, y0 = cell >> 16;
+                // (entries are ordered by the FINEST level's cell: a coarser level's x0 may step back by one inside a fine cell)
+                if (is_time && y0 == ybase && x0 >= xbase && x0 + dx - xbase < HEX_TCOL) {
+                    float* t0 = tile + ((x0 - xbase) * 2) * lanes + sub;
+                    unsafeAtomicAdd(t0, a00);
+                    unsafeAtomicAdd(t0 + 2 * dx * lanes, a01);
+                    unsafeAtomicAdd(t0 + dy * lanes, a10);
+                    unsafeAtomicAdd(t0 + (2 * dx + dy) * lanes, a11);
+                    return;
+                }
+                float* g0 = G + ((size_t)y0 * Ww + x0) * C + ch;
+                unsafeAtomicAdd(g0, a00);
+                unsafeAtomicAdd(g0 + (size_t)dx * C, a01);
+                unsafeAtomicAdd(g0 + (size_t)dy * Ww * C, a10);
+                unsafeAtomicAdd(g0 + ((size_t)dy * Ww + dx) * C, a11);
+            };
+            for (int e = 0; e < n; e += HEX_GATHER) {
+                float g[HEX_GATHER];
+#pragma unroll
+                for (int u = 0; u < HEX_GATHER; u++)
+                    g[u] = gbase[(size_t)myi[min(e + u, n - 1)].x * pstride + ch];
+#pragma unroll
+                for (int u = 0; u < HEX_GATHER; u++) {
+                    if (e + u >= n) break;
+                    const int4 ci = myi[e + u];
+                    const float4 cw = myw[e + u];
+                    if (ci.y != cell || ci.z != dx || ci.w != dy) {
+                        if (cell >= 0) flush();
+                        a00 = a01 = a10 = a11 = 0.f;
+                        cell = ci.y; dx = ci.z; dy = ci.w;
+                    }
+                    a00 += g[u] * cw.x; a01 += g[u] * cw.y; a10 += g[u] * cw.z; a11 += g[u] * cw.w;
+                }
+            }
+            if (cell >= 0) flush();
+        }
+        __syncthreads();
+        if (is_time) {
+            for (int k = threadIdx.x; k < HEX_TCOL * 2 * lanes; k += 256) {
+                const float v = tile[k];
+                const int c2 = k & (lanes - 1), rr = (k >> lanes_shift) & 1, col = k >> (lanes_shift + 1);
+                // the tile may reach past the plane (right / bottom border cells have dx = 0 or dy = 0 and never
+                // write there), so a non-zero slot is always a valid texel
+                if (v != 0.f) unsafeAtomicAdd(G + ((size_t)(ybase + rr) * Ww + xbase + col) * C + ch0 + c2, v);
+            }
+            __syncthreads();
         }
     }
-    if (cur >= 0 && acc != 0.f) unsafeAtomicAdd(g + (size_t)cur * n + i, acc);
 }
 
 // dL_dpoints += (coordinate gradient through the planes) * d(normalised)/d(world); the t' part is
@@ -1077,20 +1147,22 @@ __global__ __launch_bounds__(256) void ft_embed_final_kernel(int nparts, const f
     if (threadIdx.x == 0) { d_w[0] += s[0][0]; d_w[1] += s[0][1]; d_b[0] += s[0][2]; }
 }
 
-// per-workgroup partial record of the time-plane strips: [2][W][C] per level, widest time plane of the level
-static int strip_layout(const gs4d_deform_desc* d, int off[GS4D_MAX_LEVELS])
+// counting-sort geometry of the binned plane backward (see HexBins)
+static HexBins hex_bins(const gs4d_deform_desc* d)
 {
-    int total = 0;
-    for (int lv = 0; lv < GS4D_MAX_LEVELS; lv++) {
-        off[lv] = -1;
-        if (lv >= d->L) continue;
-        int wmax = 0;
-        const int tp[3] = {2, 4, 5};
-        for (int j = 0; j < 3; j++) wmax = d->plane_w[lv * 6 + tp[j]] > wmax ? d->plane_w[lv * 6 + tp[j]] : wmax;
-        off[lv] = total;
-        total += 2 * wmax * d->C;
+    HexBins B = {};
+    const int planes[HEX_SORTS] = {0, 3, 1};
+    const int bmajor[HEX_SORTS] = {0, 0, 1};
+    B.nbins = 1;
+    for (int s = 0; s < HEX_SORTS; s++) {
+        const int pl = (d->L - 1) * 6 + planes[s];
+        int sh = 0;
+        while ((long long)(((d->plane_w[pl] - 1) >> sh) + 1) * (((d->plane_h[pl] - 1) >> sh) + 1) > HEX_MAX_BINS) sh++;
+        B.plane[s] = planes[s]; B.bmajor[s] = bmajor[s]; B.shift[s] = sh;
+        const int nb = (((d->plane_w[pl] - 1) >> sh) + 1) * (((d->plane_h[pl] - 1) >> sh) + 1);
+        B.nbins = nb > B.nbins ? nb : B.nbins;
     }
-    return total;
+    return B;
 }
 
 static int validate(const gs4d_deform_desc* d, int P)
@@ -1179,8 +1251,8 @@ size_t gs4d_deform_workspace_bytes(const gs4d_deform_desc* d, int P)
 }
 
 static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l, size_t P, float** dO, float** dH1,
-                          float** dZ, float** dT, float** dfeat, float** dxyz_hex, float** dtprime, float** gtime,
-                          float** strip_part, int** strip_rows, float** slabs, size_t* slab_floats_per_job, size_t* bytes)
+                          float** dZ, float** dT, float** dfeat, float** dxyz_hex, float** dtprime, float** gsix,
+                          int** hist, int** rank, int** key, float4** rec, float** slabs, size_t* slab_floats_per_job, size_t* bytes)
 {
     char* p = base;
     gs4d_obtain(p, *dO, P * OUT_LD);
@@ -1190,10 +1262,11 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     gs4d_obtain(p, *dfeat, P * l.F);
     gs4d_obtain(p, *dxyz_hex, P * 4);                  // (dx,dy,dz,dt') per point, normalised coordinates
     gs4d_obtain(p, *dtprime, 3 * ((P + 255) / 256) + 3);   // per-workgroup partial sums for the t' embedding
-    gs4d_obtain(p, *gtime, P * d->L * 3 * d->C);           // time-plane sample gradients, spatial -> strip kernel
-    int strip_off[GS4D_MAX_LEVELS];
-    gs4d_obtain(p, *strip_part, (size_t)STRIP_WGS * 3 * strip_layout(d, strip_off));
-    gs4d_obtain(p, *strip_rows, (size_t)STRIP_WGS * 3 * GS4D_MAX_LEVELS * 2);
+    gs4d_obtain(p, *gsix, P * d->L * 6 * d->C);            // per-plane sample gradients, point kernel -> reduce kernel
+    gs4d_obtain(p, *hist, (size_t)HEX_SORTS * hex_bins(d).nbins);
+    gs4d_obtain(p, *rank, (size_t)HEX_SORTS * P);
+    gs4d_obtain(p, *key, (size_t)HEX_SORTS * P);
+    gs4d_obtain(p, *rec, (size_t)HEX_SORTS * P);
     const size_t nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
     int kmax = l.F > l.head_in[0] ? l.F : l.head_in[0];
     for (int h = 0; h < NHEAD; h++) kmax = l.head_in[h] > kmax ? l.head_in[h] : kmax;
@@ -1207,10 +1280,11 @@ size_t gs4d_deform_backward_scratch_bytes(const gs4d_deform_desc* d, int P)
 {
     if (validate(d, P)) return 0;
     const Layout l = make_layout(d);
-    float *a, *b, *c, *e, *f, *g, *h, *gt, *sp, *s;
-    int* sr;
+    float *a, *b, *c, *e, *f, *g, *h, *gt, *s;
+    int *hi, *rk, *ky;
+    float4* rc;
     size_t per = 0, bytes = 0;
-    carve_scratch(nullptr, d, l, (size_t)P, &a, &b, &c, &e, &f, &g, &h, &gt, &sp, &sr, &s, &per, &bytes);
+    carve_scratch(nullptr, d, l, (size_t)P, &a, &b, &c, &e, &f, &g, &h, &gt, &hi, &rk, &ky, &rc, &s, &per, &bytes);
     return bytes;
 }
 
@@ -1319,11 +1393,12 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
     }
     const Layout l = make_layout(d);
     Workspace w = carve_workspace(workspace, d, l, (size_t)P, nullptr);
-    float *dO, *dH1, *dZ, *dT, *dfeat, *dxyz_hex, *dtprime, *gtime, *strip_part, *slabs;
-    int* strip_rows;
+    float *dO, *dH1, *dZ, *dT, *dfeat, *dxyz_hex, *dtprime, *gsix, *slabs;
+    int *hist, *rank, *key;
+    float4* rec;
     size_t slab_per_job = 0;
-    carve_scratch(scratch, d, l, (size_t)P, &dO, &dH1, &dZ, &dT, &dfeat, &dxyz_hex, &dtprime, &gtime, &strip_part,
-                  &strip_rows, &slabs, &slab_per_job, nullptr);
+    carve_scratch(scratch, d, l, (size_t)P, &dO, &dH1, &dZ, &dT, &dfeat, &dxyz_hex, &dtprime, &gsix, &hist, &rank,
+                  &key, &rec, &slabs, &slab_per_job, nullptr);
     const int nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
 
     Gs4dProfScope* mlp_scope = new Gs4dProfScope("mlp_backward", s);
@@ -1458,20 +1533,24 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         }
         int lanes_shift = 0;
         while ((1 << lanes_shift) < (d->C < 64 ? d->C : 64)) lanes_shift++;
-        StripPlan plan;
-        const int strip_floats = strip_layout(d, plan.off);
-        int ppw = (P + STRIP_WGS - 1) / STRIP_WGS;
-        plan.points_per_wg = ppw;
-        const int nwg = (P + ppw - 1) / ppw;
-        const size_t threads = (size_t)P << lanes_shift;
-        hipLaunchKernelGGL(hexplane_backward_spatial_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P,
-                           d->C, d->L, lanes_shift, T, d->aabb, points, w.tprime, dfeat, l.F, (float4*)dxyz_hex, gtime);
-        hipLaunchKernelGGL(hexplane_backward_time_kernel, dim3(nwg, 3), dim3(256), 0, s,
-                           P, d->C, d->L, T, plan, d->aabb, points, w.tprime, gtime, strip_part, strip_rows,
-                           strip_floats);
-        if (strip_floats > 0)
-            hipLaunchKernelGGL(hexplane_strip_reduce_kernel, dim3((strip_floats + 255) / 256, 3), dim3(256), 0, s, nwg, d->C,
-                               d->L, T, plan, strip_part, strip_rows, strip_floats);
+        const HexBins B = hex_bins(d);
+        GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * HEX_SORTS * B.nbins, s));
+        int lpp_shift = 0;
+        while ((1 << lpp_shift) < d->C / 4) lpp_shift++;
+        const size_t threads = (size_t)P << lpp_shift;
+        hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P,
+                           d->C, d->L, lpp_shift, T, B, d->aabb, points, w.tprime, dfeat, l.F, (float4*)dxyz_hex, gsix,
+                           hist, rank, key);
+        hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS), dim3(1024), 0, s, B.nbins, hist);
+        hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, B.nbins, d->aabb, points,
+                           w.tprime, hist, rank, key, rec);
+        {
+            const int lanes = 1 << lanes_shift, step_entries = (256 >> lanes_shift) * HEX_RUN;
+            const size_t per_wg = (size_t)step_entries * HEX_RPW;
+            const size_t lds = 2 * sizeof(float4) * step_entries + sizeof(float) * HEX_TCOL * 2 * lanes;
+            hipLaunchKernelGGL(hexplane_backward_reduce_kernel, dim3((unsigned)(((size_t)P + per_wg - 1) / per_wg), 6 * d->L),
+                               dim3(256), lds, s, P, d->C, d->L, lanes_shift, T, rec, gsix);
+        }
         GS4D_LAUNCH_CHECK("hexplane_backward", 0, s);
         const int nred = (P + 255) / 256;
         hipLaunchKernelGGL(hexplane_coord_reduce_kernel, dim3(nred), dim3(256), 0, s, P, (const float4*)dxyz_hex, d->aabb,
