@@ -346,33 +346,38 @@ __global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
 __global__ __launch_bounds__(1024) void hexplane_bin_scan_kernel(int nbins, int* __restrict__ hist)
 {
     __shared__ int part[16];
+    __shared__ int carry_s;
     int* h = hist + (size_t)blockIdx.x * nbins;
-    // lane t owns bins t, t + 1024, ... of every 1024-bin stripe?  No: contiguous bins per lane keep the scan a
-    // plain running sum; the HEX_MAX_BINS / 1024 = 64 loads of a lane are independent and issued together.
-    const int per = (nbins + 1023) / 1024;                  // <= 64
-    const int b0 = threadIdx.x * per;
-    int v[HEX_MAX_BINS / 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int carry = 0;
+    // tiles of 4096 bins: four consecutive bins per lane, scanned inside the wave by shuffles and across the
+    // 16 waves through LDS (no per-lane arrays: a spilling kernel pays a scratch set-up on every dispatch)
+    for (int t0 = 0; t0 < nbins; t0 += 4096) {
+        const int b = t0 + 4 * threadIdx.x;
+        int v0 = b < nbins ? h[b] : 0, v1 = b + 1 < nbins ? h[b + 1] : 0;
+        int v2 = b + 2 < nbins ? h[b + 2] : 0, v3 = b + 3 < nbins ? h[b + 3] : 0;
+        const int s = v0 + v1 + v2 + v3;
+        int inc = s;
 #pragma unroll
-    for (int k = 0; k < HEX_MAX_BINS / 1024; k++) v[k] = (k < per && b0 + k < nbins) ? h[b0 + k] : 0;
-    int s = 0;
-#pragma unroll
-    for (int k = 0; k < HEX_MAX_BINS / 1024; k++) s += v[k];
-    // inclusive scan of the lane sums: inside the wave by shuffles, across the 16 waves through LDS
-    int inc = s;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int u = __shfl_up(inc, off, 64);
-        if ((int)(threadIdx.x & 63) >= off) inc += u;
-    }
-    if ((threadIdx.x & 63) == 63) part[threadIdx.x >> 6] = inc;
-    __syncthreads();
-    int wave_prefix = 0;
-    for (int w = 0; w < (int)(threadIdx.x >> 6); w++) wave_prefix += part[w];
-    int run = wave_prefix + inc - s;
-#pragma unroll
-    for (int k = 0; k < HEX_MAX_BINS / 1024; k++) {
-        if (k < per && b0 + k < nbins) h[b0 + k] = run;
-        run += v[k];
+        for (int off = 1; off < 64; off <<= 1) {
+            const int u = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += u;
+        }
+        if (lane == 63) part[wave] = inc;
+        __syncthreads();
+        int prefix = carry;
+        for (int w = 0; w < wave; w++) prefix += part[w];
+        if (threadIdx.x == 1023) carry_s = prefix + inc;
+        int run = prefix + inc - s;
+        if (b < nbins) h[b] = run;
+        run += v0;
+        if (b + 1 < nbins) h[b + 1] = run;
+        run += v1;
+        if (b + 2 < nbins) h[b + 2] = run;
+        run += v2;
+        if (b + 3 < nbins) h[b + 3] = run;
+        __syncthreads();
+        carry = carry_s;
     }
 }
 
@@ -401,28 +406,29 @@ __global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int nb
     }
 }
 
-// blockIdx.y = level * 6 + plane.  min(C, 64) lanes (one per channel) walk runs of HEX_RUN sorted points; a
-// workgroup owns HEX_RPW * (256 / lanes) consecutive runs.  Per HEX_RPW step the corners of the step's entries
-// are computed once (one lane per entry) into LDS; the gradient rows are gathered eight entries at a time.
-// Same-line memory-side atomics serialise at ~0.5 us each (measured: the 128 hot texel rows of a coarse time
-// plane cost 57 us when every run flushed to memory), so the time planes -- whose points all sit in the same
-// two texel rows -- flush into a small LDS tile [HEX_TCOL columns][2 rows] anchored at the workgroup's first
-// entry and the tile goes to memory once per workgroup; anything outside the tile (other rows: per-point
-// timestamps; farther columns: sparse regions) takes the direct atomic.
-#define HEX_GATHER 8
+// blockIdx.y = level * 6 + plane.  A group of min(C, 64) lanes (one per channel) walks HEX_RPW * HEX_RUN
+// consecutive sorted points, a workgroup 256 / lanes such groups (consecutive ranges).  Per step of HEX_RUN
+// points the corners are computed once per entry (one lane each, next step's records already in flight) into
+// LDS and the HEX_RUN gradient rows of the step are gathered together.  A group keeps the four corner sums of
+// its current cell in registers across steps, steps by one texel along the sort's minor axis keep the two
+// shared corners, and memory is touched only when the cell really changes.  What a group still holds at its
+// end is merged with its neighbours' through LDS (plain stores: measured, ds_add_f32 tiles cost more than the
+// memory atomics they saved), so a cell spanning the whole workgroup -- every time plane, whose points share
+// two texel rows -- reaches memory once per workgroup.  Same-line memory-side atomics serialise at ~0.5 us
+// each: the 128 hot rows of the coarse time planes alone cost 57 us when every run flushed to memory.
 #define HEX_RPW 4
-#define HEX_TCOL 16
-__global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, int C, int L, int lanes_shift, PlaneTable T,
+#define HEX_GATHER 16
+template <int lanes_shift>
+__global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, int C, int L, PlaneTable T,
                                                                        const float4* __restrict__ rec,
                                                                        const float* __restrict__ gsix)
 {
-    extern __shared__ float4 s_mem[];                       // corner weights | corner indices | tile
+    extern __shared__ float4 s_mem[];                       // corner weights | corner indices | end-of-group partials
     const int lanes = 1 << lanes_shift;
     const int pl = blockIdx.y, l = pl / 6, i = pl % 6;
-    const bool is_time = i == 2 || i == 4 || i == 5;
-    const int runs_wg = 256 >> lanes_shift;
-    const int step_entries = runs_wg * HEX_RUN;
-    const int lrun = threadIdx.x >> lanes_shift;
+    const int groups = 256 >> lanes_shift;
+    const int step_entries = groups * HEX_RUN;
+    const int grp = threadIdx.x >> lanes_shift;
     const int sub = threadIdx.x & (lanes - 1);
     const float4* __restrict__ R = rec + (size_t)kSortOf[i] * P;
     const size_t wg_e0 = (size_t)blockIdx.x * step_entries * HEX_RPW;
@@ -431,91 +437,112 @@ __global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, in
     const int selA = kSelA[i], selB = kSelB[i];
     float4* s_w = s_mem;
     int4* s_i = reinterpret_cast<int4*>(s_mem + step_entries);
-    float* tile = reinterpret_cast<float*>(s_mem + 2 * step_entries);     // [HEX_TCOL][2][lanes]
-    int xbase, ybase;
-    {
-        const float4 r = R[wg_e0];
-        const float f[3] = {r.y, r.z, r.w};
-        const Corner c = corner_of(f[selA], f[selB], Ww, Hh);
-        xbase = c.x0; ybase = c.y0;
-    }
+    float* s_part = reinterpret_cast<float*>(s_mem + 2 * step_entries);   // [groups][4][lanes]
+    int* s_cell = reinterpret_cast<int*>(s_part + 4 * 256);               // [groups][3]
     float* __restrict__ G = T.g[pl];
     const float* __restrict__ gbase = gsix + ((size_t)l * 6 + i) * C;
     const size_t pstride = (size_t)L * 6 * C;
+    // staging slot k of a step belongs to group k / HEX_RUN, entry k % HEX_RUN of that group's step
+    constexpr int per_thread = lanes_shift >= 5 ? 1 : (32 >> lanes_shift);   // staging slots per thread: 1 (lanes >= 32) .. 8 (lanes = 4)
+    auto entry_of = [&](int it, int k) { return wg_e0 + ((size_t)(k / HEX_RUN) * HEX_RPW + it) * HEX_RUN + (k % HEX_RUN); };
+
     for (int ch0 = 0; ch0 < C; ch0 += lanes) {
         const int ch = ch0 + sub;
-        if (is_time) {
-            for (int k = threadIdx.x; k < HEX_TCOL * 2 * lanes; k += 256) tile[k] = 0.f;
-        }
-        for (int it = 0; it < HEX_RPW; it++) {
-            const size_t st_e0 = wg_e0 + (size_t)it * step_entries;
-            __syncthreads();                                // previous step's readers are done (and the tile is zeroed)
-            if (st_e0 >= (size_t)P) break;                  // uniform
-            // the corner of an entry is the same for every channel: computed once per entry, by one lane
-            for (int k = threadIdx.x; k < step_entries; k += 256) {
-                if (st_e0 + k >= (size_t)P) break;
-                const float4 r = R[st_e0 + k];
-                const float f[3] = {r.y, r.z, r.w};
-                const Corner c = corner_of(f[selA], f[selB], Ww, Hh);
-                s_w[k] = make_float4(c.w00, c.w01, c.w10, c.w11);
-                s_i[k] = make_int4(__float_as_int(r.x), c.x0 | (c.y0 << 16), c.x1 - c.x0, c.y1 - c.y0);
+        float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+        int cell = -1, dx = 0, dy = 0;
+        auto flush = [&]() {
+            float* g0 = G + ((size_t)(cell >> 16) * Ww + (cell & 0xFFFF)) * C + ch;
+            unsafeAtomicAdd(g0, a00);
+            unsafeAtomicAdd(g0 + (size_t)dx * C, a01);
+            unsafeAtomicAdd(g0 + (size_t)dy * Ww * C, a10);
+            unsafeAtomicAdd(g0 + ((size_t)dy * Ww + dx) * C, a11);
+        };
+        float4 rn[per_thread];
+#pragma unroll
+        for (int j = 0; j < per_thread; j++)
+            {
+                const int k = threadIdx.x + 256 * j;
+                rn[j] = R[min(entry_of(0, min(k, step_entries - 1)), (size_t)P - 1)];
             }
+        for (int it = 0; it < HEX_RPW; it++) {
+            __syncthreads();                                // the previous step's readers are done
+#pragma unroll
+            for (int j = 0; j < per_thread; j++)
+                {
+                    const int k = threadIdx.x + 256 * j;
+                    if (k < step_entries) {
+                        const float f[3] = {rn[j].y, rn[j].z, rn[j].w};
+                        const Corner c = corner_of(f[selA], f[selB], Ww, Hh);
+                        s_w[k] = make_float4(c.w00, c.w01, c.w10, c.w11);
+                        s_i[k] = make_int4(__float_as_int(rn[j].x), c.x0 | (c.y0 << 16), c.x1 - c.x0, c.y1 - c.y0);
+                    }
+                }
             __syncthreads();
-            const size_t e0 = st_e0 + (size_t)lrun * HEX_RUN;
+            if (it + 1 < HEX_RPW) {
+#pragma unroll
+                for (int j = 0; j < per_thread; j++)
+                    {
+                        const int k = threadIdx.x + 256 * j;
+                        rn[j] = R[min(entry_of(it + 1, min(k, step_entries - 1)), (size_t)P - 1)];
+                    }
+            }
+            const size_t e0 = wg_e0 + ((size_t)grp * HEX_RPW + it) * HEX_RUN;
             if (e0 >= (size_t)P) continue;
             const int n = (int)min((size_t)HEX_RUN, (size_t)P - e0);
-            const float4* __restrict__ myw = s_w + lrun * HEX_RUN;
-            const int4* __restrict__ myi = s_i + lrun * HEX_RUN;
-            float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
-            int cell = -1, dx = 0, dy = 0;
-            auto flush = [&]() {
-                const int x0 = cell & 0xFFFF, y0 = cell >> 16;
-                // (entries are ordered by the FINEST level's cell: a coarser level's x0 may step back by one inside a fine cell)
-                if (is_time && y0 == ybase && x0 >= xbase && x0 + dx - xbase < HEX_TCOL) {
-                    float* t0 = tile + ((x0 - xbase) * 2) * lanes + sub;
-                    unsafeAtomicAdd(t0, a00);
-                    unsafeAtomicAdd(t0 + 2 * dx * lanes, a01);
-                    unsafeAtomicAdd(t0 + dy * lanes, a10);
-                    unsafeAtomicAdd(t0 + (2 * dx + dy) * lanes, a11);
-                    return;
-                }
-                float* g0 = G + ((size_t)y0 * Ww + x0) * C + ch;
-                unsafeAtomicAdd(g0, a00);
-                unsafeAtomicAdd(g0 + (size_t)dx * C, a01);
-                unsafeAtomicAdd(g0 + (size_t)dy * Ww * C, a10);
-                unsafeAtomicAdd(g0 + ((size_t)dy * Ww + dx) * C, a11);
-            };
+            const float4* __restrict__ myw = s_w + grp * HEX_RUN;
+            const int4* __restrict__ myi = s_i + grp * HEX_RUN;
             for (int e = 0; e < n; e += HEX_GATHER) {
                 float g[HEX_GATHER];
 #pragma unroll
-                for (int u = 0; u < HEX_GATHER; u++)
-                    g[u] = gbase[(size_t)myi[min(e + u, n - 1)].x * pstride + ch];
+                for (int u = 0; u < HEX_GATHER; u++) g[u] = gbase[(size_t)myi[min(e + u, n - 1)].x * pstride + ch];
 #pragma unroll
                 for (int u = 0; u < HEX_GATHER; u++) {
                     if (e + u >= n) break;
                     const int4 ci = myi[e + u];
                     const float4 cw = myw[e + u];
                     if (ci.y != cell || ci.z != dx || ci.w != dy) {
-                        if (cell >= 0) flush();
-                        a00 = a01 = a10 = a11 = 0.f;
+                        if (cell >= 0 && ci.z == dx && ci.w == dy && ci.y == cell + 0x10000 && dy == 1) {
+                            float* g0 = G + ((size_t)(cell >> 16) * Ww + (cell & 0xFFFF)) * C + ch;
+                            unsafeAtomicAdd(g0, a00);
+                            unsafeAtomicAdd(g0 + (size_t)dx * C, a01);
+                            a00 = a10; a01 = a11; a10 = a11 = 0.f;
+                        } else if (cell >= 0 && ci.z == dx && ci.w == dy && ci.y == cell + 1 && dx == 1) {
+                            float* g0 = G + ((size_t)(cell >> 16) * Ww + (cell & 0xFFFF)) * C + ch;
+                            unsafeAtomicAdd(g0, a00);
+                            unsafeAtomicAdd(g0 + (size_t)dy * Ww * C, a10);
+                            a00 = a01; a10 = a11; a01 = a11 = 0.f;
+                        } else {
+                            if (cell >= 0) flush();
+                            a00 = a01 = a10 = a11 = 0.f;
+                        }
                         cell = ci.y; dx = ci.z; dy = ci.w;
                     }
                     a00 += g[u] * cw.x; a01 += g[u] * cw.y; a10 += g[u] * cw.z; a11 += g[u] * cw.w;
                 }
             }
+        }
+        // merge what the groups still hold, in group (= sorted) order, by the lanes of group 0
+        s_part[(grp * 4 + 0) * lanes + sub] = a00; s_part[(grp * 4 + 1) * lanes + sub] = a01;
+        s_part[(grp * 4 + 2) * lanes + sub] = a10; s_part[(grp * 4 + 3) * lanes + sub] = a11;
+        if (sub == 0) { s_cell[grp * 3] = cell; s_cell[grp * 3 + 1] = dx; s_cell[grp * 3 + 2] = dy; }
+        __syncthreads();
+        if (grp == 0) {
+            a00 = a01 = a10 = a11 = 0.f;
+            cell = -1;
+            for (int r = 0; r < groups; r++) {
+                const int rc = s_cell[r * 3], rdx = s_cell[r * 3 + 1], rdy = s_cell[r * 3 + 2];
+                if (rc < 0) continue;
+                if (rc != cell || rdx != dx || rdy != dy) {
+                    if (cell >= 0) flush();
+                    a00 = a01 = a10 = a11 = 0.f;
+                    cell = rc; dx = rdx; dy = rdy;
+                }
+                a00 += s_part[(r * 4 + 0) * lanes + sub]; a01 += s_part[(r * 4 + 1) * lanes + sub];
+                a10 += s_part[(r * 4 + 2) * lanes + sub]; a11 += s_part[(r * 4 + 3) * lanes + sub];
+            }
             if (cell >= 0) flush();
         }
         __syncthreads();
-        if (is_time) {
-            for (int k = threadIdx.x; k < HEX_TCOL * 2 * lanes; k += 256) {
-                const float v = tile[k];
-                const int c2 = k & (lanes - 1), rr = (k >> lanes_shift) & 1, col = k >> (lanes_shift + 1);
-                // the tile may reach past the plane (right / bottom border cells have dx = 0 or dy = 0 and never
-                // write there), so a non-zero slot is always a valid texel
-                if (v != 0.f) unsafeAtomicAdd(G + ((size_t)(ybase + rr) * Ww + xbase + col) * C + ch0 + c2, v);
-            }
-            __syncthreads();
-        }
     }
 }
 
@@ -1545,11 +1572,20 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, B.nbins, d->aabb, points,
                            w.tprime, hist, rank, key, rec);
         {
-            const int lanes = 1 << lanes_shift, step_entries = (256 >> lanes_shift) * HEX_RUN;
+            const int step_entries = (256 >> lanes_shift) * HEX_RUN;
             const size_t per_wg = (size_t)step_entries * HEX_RPW;
-            const size_t lds = 2 * sizeof(float4) * step_entries + sizeof(float) * HEX_TCOL * 2 * lanes;
-            hipLaunchKernelGGL(hexplane_backward_reduce_kernel, dim3((unsigned)(((size_t)P + per_wg - 1) / per_wg), 6 * d->L),
-                               dim3(256), lds, s, P, d->C, d->L, lanes_shift, T, rec, gsix);
+            const size_t lds = 2 * sizeof(float4) * step_entries + sizeof(float) * 4 * 256 + sizeof(int) * 3 * 64;
+            void (*kern)(int, int, int, PlaneTable, const float4*, const float*) =
+                lanes_shift == 2 ? hexplane_backward_reduce_kernel<2> : lanes_shift == 3 ? hexplane_backward_reduce_kernel<3> :
+                lanes_shift == 4 ? hexplane_backward_reduce_kernel<4> : lanes_shift == 5 ? hexplane_backward_reduce_kernel<5> :
+                                   hexplane_backward_reduce_kernel<6>;
+            static bool reduce_attr[8] = {};
+            if (!reduce_attr[lanes_shift]) {
+                GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+                reduce_attr[lanes_shift] = true;
+            }
+            hipLaunchKernelGGL(kern, dim3((unsigned)(((size_t)P + per_wg - 1) / per_wg), 6 * d->L), dim3(256), lds, s, P, d->C,
+                               d->L, T, rec, gsix);
         }
         GS4D_LAUNCH_CHECK("hexplane_backward", 0, s);
         const int nred = (P + 255) / 256;
