@@ -241,9 +241,11 @@ __device__ __forceinline__ SixSamples six_samples(const PlaneTable& T, int l, in
 #define HEX_RUN 32
 #define HEX_MAX_BINS 65536
 struct HexBins {
-    int plane[HEX_SORTS];      // finest-level plane whose cells order sort s: xy, yz, xz
+    int plane[HEX_SORTS];      // plane whose cells order sort s of a level: xy, yz, xz (one sort per level and plane:
+                               // the levels' cells do not nest -- 63 vs 127 intervals -- so a finest-level order makes a coarse
+                               // level flip between two cells inside every fine cell: measured 116k atomic rows instead of 10k)
     int bmajor[HEX_SORTS];     // 1: key = y0 * W + x0 (B-major), 0: key = x0 * H + y0
-    int shift[HEX_SORTS];      // cells are coarsened by this many bits if the plane has more than HEX_MAX_BINS cells
+    int shift[GS4D_MAX_LEVELS][HEX_SORTS];   // per level: cells are coarsened by this many bits if the plane has more than HEX_MAX_BINS cells
     int nbins;                 // bins per sort (max over the sorts)
 };
 // plane i of a level is served by sort kSortOf[i]; its (A, B) coordinates are fields kSelA/kSelB of the sorted
@@ -252,9 +254,9 @@ __device__ __constant__ const int kSortOf[6] = {0, 2, 0, 1, 1, 2};
 __device__ __constant__ const int kSelA[6] = {0, 0, 0, 0, 0, 1};
 __device__ __constant__ const int kSelB[6] = {1, 1, 2, 1, 2, 2};
 
-__device__ __forceinline__ int hex_key(const HexBins& B, int s, int x0, int y0, int Ww, int Hh)
+__device__ __forceinline__ int hex_key(const HexBins& B, int l, int s, int x0, int y0, int Ww, int Hh)
 {
-    const int sh = B.shift[s];
+    const int sh = B.shift[l][s];
     const int xs = x0 >> sh, ys = y0 >> sh;
     const int ws = ((Ww - 1) >> sh) + 1, hs = ((Hh - 1) >> sh) + 1;
     return B.bmajor[s] ? ys * ws + xs : xs * hs + ys;
@@ -266,8 +268,8 @@ __global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
     const float* __restrict__ xyz, const float* __restrict__ tprime, const float* __restrict__ dfeat, int ldf,
     float4* __restrict__ dcoord,               // [P]: (d/dx, d/dy, d/dz, d/dt') in normalised coordinates
     float* __restrict__ gsix,                  // [P][L][6][C]: dL/d(sample) of every plane
-    int* __restrict__ hist,                    // [HEX_SORTS][nbins], zeroed by the caller
-    int* __restrict__ rank, int* __restrict__ key)   // [HEX_SORTS][P]
+    int* __restrict__ hist,                    // [L][HEX_SORTS][nbins], zeroed by the caller
+    int* __restrict__ rank, int* __restrict__ key)   // [L][HEX_SORTS][P]
 {
     const int lanes = 1 << lpp_shift;
     const int gtid = blockIdx.x * 256 + threadIdx.x;
@@ -285,18 +287,18 @@ __global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
         pts[3] = tprime[p];
     }
     float dpts[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live && sub == 0) {                     // rank the point inside its finest-level cell of every sort plane
-#pragma unroll
-        for (int s = 0; s < HEX_SORTS; s++) {
-            const int i = B.plane[s], pl = (L - 1) * 6 + i;
+    if (live) {                                 // rank the point inside its cell of every level's sort planes
+        for (int ls = sub; ls < L * HEX_SORTS; ls += lanes) {    // one (level, sort) per lane of the point
+            const int l = ls / HEX_SORTS, s = ls - l * HEX_SORTS;
+            const int i = B.plane[s], pl = l * 6 + i;
             float u = 0.f, v = 0.f;
 #pragma unroll
             for (int k = 0; k < 6; k++)
                 if (k == i) { u = pts[kPairA[k]]; v = pts[kPairB[k]]; }
             const Corner c = corner_of(u, v, T.w[pl], T.h[pl]);
-            const int k = hex_key(B, s, c.x0, c.y0, T.w[pl], T.h[pl]);
-            key[(size_t)s * P + p] = k;
-            rank[(size_t)s * P + p] = atomicAdd(&hist[s * B.nbins + k], 1);
+            const int k = hex_key(B, l, s, c.x0, c.y0, T.w[pl], T.h[pl]);
+            key[(size_t)ls * P + p] = k;
+            rank[(size_t)ls * P + p] = atomicAdd(&hist[(size_t)ls * B.nbins + k], 1);
         }
     }
     if (live) {
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(1024) void hexplane_bin_scan_kernel(int nbins, int*
 }
 
 // sorted record of sort s at position start[key] + rank: (p, a, b, t') with (a, b) = (x,y), (y,z), (x,z)
-__global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int nbins, const float* __restrict__ aabb,
+__global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int L, int nbins, const float* __restrict__ aabb,
                                                                    const float* __restrict__ xyz,
                                                                    const float* __restrict__ tprime,
                                                                    const int* __restrict__ start,
@@ -399,10 +401,13 @@ __global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int nb
     }
     const float t = tprime[p];
     const float ra[HEX_SORTS] = {pts[0], pts[1], pts[0]}, rb[HEX_SORTS] = {pts[1], pts[2], pts[2]};
+    for (int l = 0; l < L; l++) {
 #pragma unroll
-    for (int s = 0; s < HEX_SORTS; s++) {
-        const int pos = start[s * nbins + key[(size_t)s * P + p]] + rank[(size_t)s * P + p];
-        rec[(size_t)s * P + pos] = make_float4(__int_as_float(p), ra[s], rb[s], t);
+        for (int s = 0; s < HEX_SORTS; s++) {
+            const size_t ls = (size_t)l * HEX_SORTS + s;
+            const int pos = start[ls * nbins + key[ls * P + p]] + rank[ls * P + p];
+            rec[ls * P + pos] = make_float4(__int_as_float(p), ra[s], rb[s], t);
+        }
     }
 }
 
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, in
     const int step_entries = groups * HEX_RUN;
     const int grp = threadIdx.x >> lanes_shift;
     const int sub = threadIdx.x & (lanes - 1);
-    const float4* __restrict__ R = rec + (size_t)kSortOf[i] * P;
+    const float4* __restrict__ R = rec + ((size_t)l * HEX_SORTS + kSortOf[i]) * P;
     const size_t wg_e0 = (size_t)blockIdx.x * step_entries * HEX_RPW;
     if (wg_e0 >= (size_t)P) return;                         // uniform
     const int Ww = T.w[pl], Hh = T.h[pl];
@@ -1182,12 +1187,15 @@ static HexBins hex_bins(const gs4d_deform_desc* d)
     const int bmajor[HEX_SORTS] = {0, 0, 1};
     B.nbins = 1;
     for (int s = 0; s < HEX_SORTS; s++) {
-        const int pl = (d->L - 1) * 6 + planes[s];
-        int sh = 0;
-        while ((long long)(((d->plane_w[pl] - 1) >> sh) + 1) * (((d->plane_h[pl] - 1) >> sh) + 1) > HEX_MAX_BINS) sh++;
-        B.plane[s] = planes[s]; B.bmajor[s] = bmajor[s]; B.shift[s] = sh;
-        const int nb = (((d->plane_w[pl] - 1) >> sh) + 1) * (((d->plane_h[pl] - 1) >> sh) + 1);
-        B.nbins = nb > B.nbins ? nb : B.nbins;
+        B.plane[s] = planes[s]; B.bmajor[s] = bmajor[s];
+        for (int lv = 0; lv < d->L; lv++) {
+            const int pl = lv * 6 + planes[s];
+            int sh = 0;
+            while ((long long)(((d->plane_w[pl] - 1) >> sh) + 1) * (((d->plane_h[pl] - 1) >> sh) + 1) > HEX_MAX_BINS) sh++;
+            B.shift[lv][s] = sh;
+            const int nb = (((d->plane_w[pl] - 1) >> sh) + 1) * (((d->plane_h[pl] - 1) >> sh) + 1);
+            B.nbins = nb > B.nbins ? nb : B.nbins;
+        }
     }
     return B;
 }
@@ -1290,10 +1298,10 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     gs4d_obtain(p, *dxyz_hex, P * 4);                  // (dx,dy,dz,dt') per point, normalised coordinates
     gs4d_obtain(p, *dtprime, 3 * ((P + 255) / 256) + 3);   // per-workgroup partial sums for the t' embedding
     gs4d_obtain(p, *gsix, P * d->L * 6 * d->C);            // per-plane sample gradients, point kernel -> reduce kernel
-    gs4d_obtain(p, *hist, (size_t)HEX_SORTS * hex_bins(d).nbins);
-    gs4d_obtain(p, *rank, (size_t)HEX_SORTS * P);
-    gs4d_obtain(p, *key, (size_t)HEX_SORTS * P);
-    gs4d_obtain(p, *rec, (size_t)HEX_SORTS * P);
+    gs4d_obtain(p, *hist, (size_t)d->L * HEX_SORTS * hex_bins(d).nbins);
+    gs4d_obtain(p, *rank, (size_t)d->L * HEX_SORTS * P);
+    gs4d_obtain(p, *key, (size_t)d->L * HEX_SORTS * P);
+    gs4d_obtain(p, *rec, (size_t)d->L * HEX_SORTS * P);
     const size_t nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
     int kmax = l.F > l.head_in[0] ? l.F : l.head_in[0];
     for (int h = 0; h < NHEAD; h++) kmax = l.head_in[h] > kmax ? l.head_in[h] : kmax;
@@ -1561,15 +1569,15 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         int lanes_shift = 0;
         while ((1 << lanes_shift) < (d->C < 64 ? d->C : 64)) lanes_shift++;
         const HexBins B = hex_bins(d);
-        GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * HEX_SORTS * B.nbins, s));
+        GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * d->L * HEX_SORTS * B.nbins, s));
         int lpp_shift = 0;
         while ((1 << lpp_shift) < d->C / 4) lpp_shift++;
         const size_t threads = (size_t)P << lpp_shift;
         hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P,
                            d->C, d->L, lpp_shift, T, B, d->aabb, points, w.tprime, dfeat, l.F, (float4*)dxyz_hex, gsix,
                            hist, rank, key);
-        hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS), dim3(1024), 0, s, B.nbins, hist);
-        hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, B.nbins, d->aabb, points,
+        hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS * d->L), dim3(1024), 0, s, B.nbins, hist);
+        hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, d->L, B.nbins, d->aabb, points,
                            w.tprime, hist, rank, key, rec);
         {
             const int step_entries = (256 >> lanes_shift) * HEX_RUN;
