@@ -101,6 +101,8 @@ class _DeformFunction(torch.autograd.Function):
         time_, force_ = f32(time).reshape(-1), f32(force).reshape(-1)
         if rot_.data_ptr() % 16:
             rot_ = rot_.clone()
+        if shs_.data_ptr() % 16:
+            shs_ = shs_.clone()
         planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
         d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
         o_xyz, o_sc, o_rot, o_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, shs_))
@@ -146,6 +148,8 @@ class _DeformFunction(torch.autograd.Function):
         g_shs = gz(g_shs, torch.empty(P, 16, 3, device=dev))
         if g_rot.data_ptr() % 16:
             g_rot = g_rot.clone()
+        if g_shs.data_ptr() % 16:
+            g_shs = g_shs.clone()
         d_xyz, d_sc, d_rot, d_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, g_shs))
         scratch = torch.empty(max(int(L.gs4d_deform_backward_scratch_bytes(C.byref(d), C.c_int(P))), 256),
                               dtype=torch.uint8, device=dev)

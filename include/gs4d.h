@@ -223,6 +223,7 @@ size_t gs4d_deform_backward_scratch_bytes(const gs4d_deform_desc* d, int P);
 
 /* points [P,3], scales [P,3], rotations [P,4], shs [P,16,3], time [P], force [P] ->
  * out_means3D [P,3], out_scales [P,3], out_rotations [P,4], out_shs [P,16,3].
+ * rotations, shs, out_rotations and out_shs must be 16-byte aligned (float4 accesses).
  * workspace: gs4d_deform_workspace_bytes(), 256-byte aligned, kept by the caller for the backward. */
 int gs4d_deform_forward(const gs4d_deform_desc* d, int P,
                         const float* points, const float* scales, const float* rotations, const float* shs,
