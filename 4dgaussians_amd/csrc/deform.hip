@@ -1488,7 +1488,7 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         rc = launch_gemm(P, jobs, NHEAD, s);
         if (rc) return rc;
     }
-    // dZ = (sum_h dH1_h W1_h scattered to Z columns) * (Z > 0): five disjoint column groups
+    // dZ = (sum_h dH1_h W1_h scattered to Z columns) * (Z > 0): the hidden columns and the three PE segments
     {
         GemmJobs jobs = {};
         int nj = 0;
@@ -1503,9 +1503,8 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         };
         int hid[NHEAD] = {0, 0, 0, 0};
         all_heads(0, WIDTH, hid);
-        int tf[NHEAD];
-        for (int h = 0; h < NHEAD; h++) tf[h] = l.head_in[h] - l.e;
-        all_heads(l.oT, l.e, tf);
+        // the time / force embedding columns of dZ are never consumed (time and force are inputs, not
+        // parameters, and t' reaches the planes through force_time_embed, not through these columns): not computed
         for (int h = 0; h < 3; h++) {
             if (l.head_seglen[h] == 0) continue;
             GemmJob& j = jobs.j[nj++];

@@ -154,7 +154,9 @@ def main():
 
     def train_step():
         image, *_ = R.render(cam, pc, deform, bg)
-        loss = F.l1_loss(image, target) / world           # SUM over ranks == mean over the global batch
+        loss = F.l1_loss(image, target)
+        if world > 1:
+            loss = loss / world                           # SUM over ranks == mean over the global batch
         loss.backward()
         if world > 1:
             gauss_bucket.all_reduce(async_op=True)        # overlaps with packing the second bucket
