@@ -20,11 +20,13 @@
 //    rot PE | time emb | force emb]; every head reads its inputs as column segments of Z, so no
 //    torch.cat copies exist;
 //  * every Linear is a 128-row x 64-column workgroup tile on the exact-f32 MFMA (bit-for-bit an
-//    fmaf chain, so parity with the fp32 reference holds to ~1e-6), operands staged through LDS
-//    with a 33-float row pitch (conflict-free ds_read_b32 for the A fragment);
+//    fmaf chain, so parity with the fp32 reference holds to ~1e-6): A streamed from global memory
+//    into registers, B resident in LDS (see gemm_rows_kernel);
 //  * weight gradients reduce over the points with the same MFMA (K = points), one partial slab
-//    per 512-point chunk and a fixed-order slab sum (deterministic); plane gradients use float
-//    atomics (the only non-deterministic sums in the library).
+//    per 512-point chunk and a fixed-order slab sum (deterministic);
+//  * plane gradients: points are binned by texel cell (counting sort), their adds combined in
+//    registers per cell, and only the combined rows go to memory with float atomics (the only
+//    non-deterministic sums in the library).
 #include "gs4d_internal.h"
 
 #define WIDTH 64            // net_width of every supported config
