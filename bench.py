@@ -19,6 +19,9 @@ One JSON line is printed by rank 0.  Besides the contract fields it carries
   cpu_baseline  -- the CPU oracle (scalar C rasterizer + PyTorch-CPU deformation) on one core for the
                    same workload, rank 0 / N == 1 only
   stages_ms     -- average device milliseconds of every kernel stage (same HIP-event mechanism)
+  with_optimizer -- (train mode) the same iteration plus the HexPlane grid regularisers in the loss and one fused
+                   AdamW step over all parameters ("report optimizer-inclusive separately"),
+                   timed in its own loop AFTER everything else (it changes the parameters)
 """
 from __future__ import annotations
 
@@ -45,7 +48,7 @@ FP32_PEAK_TFLOPS = 157.3   # vector / f32-MFMA peak
 
 STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges",
           "blend_forward", "l1_loss_forward", "l1_loss_backward", "blend_backward", "geom_backward",
-          "activate_backward", "mlp_backward", "hexplane_backward")
+          "activate_backward", "mlp_backward", "hexplane_backward", "plane_reg_forward", "plane_reg_backward", "adamw")
 
 
 def deform_args(name: str):
@@ -74,6 +77,7 @@ def main():
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (then the line is not the headline config)")
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer-pass", action="store_true", help="skip the separate optimizer-inclusive timing loop")
     ap.add_argument("--no-stage-events", action="store_true",
                     help="do not record per-stage HIP events in the timed region (then no roofline / stages_ms)")
     args = ap.parse_args()
@@ -288,6 +292,54 @@ def main():
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
         }
+    # optimizer-inclusive iteration (all ranks; after every other measurement because it moves the parameters)
+    with_opt = None
+    if args.mode == "train" and not args.no_optimizer_pass:
+        opt_mod = importlib.import_module("4dgaussians_amd.optim")
+        reg = importlib.import_module("4dgaussians_amd.scene.regulation")
+        # learning rates / weights: arguments/__init__.py OptimizationParams defaults of the reference
+        opt = opt_mod.FusedAdamW([
+            {"params": [pc._xyz], "lr": 0.00016, "name": "xyz"},
+            {"params": list(deform.get_mlp_parameters()), "lr": 0.00016, "name": "deformation"},
+            {"params": list(deform.get_grid_parameters()), "lr": 0.0016, "name": "grid"},
+            {"params": [pc._features], "lr": 0.0025, "name": "f_dc"},
+            {"params": [pc._opacity], "lr": 0.05, "name": "opacity"},
+            {"params": [pc._scaling], "lr": 0.005, "name": "scaling"},
+            {"params": [pc._rotation], "lr": 0.001, "name": "rotation"}], lr=0.0001, eps=1e-8)
+
+        def opt_step():
+            image, *_ = R.render(cam, pc, deform, bg)
+            loss = F.l1_loss(image, target) + reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
+            if world > 1:
+                loss = loss / world
+            loss.backward()
+            if world > 1:
+                gauss_bucket.all_reduce(async_op=True)
+                deform_bucket.all_reduce(async_op=True)
+                gauss_bucket.finish()
+                deform_bucket.finish()
+            opt.step()
+            for p in all_params:
+                p.grad = None
+
+        for _ in range(args.warmup):
+            opt_step()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            opt_step()
+        sync()
+        dto = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dto], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dto = float(t.item())
+        with_opt = {"value": round(world * args.steps / dto, 3), "unit": "view-iterations/s (fwd+bwd+regularisers+AdamW)",
+                    "ms_per_step": round(dto / args.steps * 1e3, 4),
+                    "note": "same iteration + HexPlane grid regularisers (scene/gaussian_model.py:679-706) + one fused AdamW "
+                            "step over all parameters (scene/gaussian_model.py:195-206); not the headline metric"}
+    if rank == 0:
+        out["with_optimizer"] = with_opt
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -259,6 +259,55 @@ size_t gs4d_l1_loss_scratch_bytes(void);
 int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream);
 int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float* g_loss, float* d_a, void* stream);
 
+/* ---- optimizer step and grid regularisers (the per-iteration work right after the render path;
+ * SURVEY.md section 8(f) rank 2) ----
+ *
+ * gs4d_adamw_step: torch.optim.AdamW as constructed at scene/gaussian_model.py:206 (decoupled weight decay,
+ * no amsgrad) for a list of parameter tensors in ONE launch; the reference calls optimizer.step() at
+ * train.py:328.  Per tensor the caller supplies this step's learning rate (the per-group schedules of
+ * scene/gaussian_model.py:228-242), weight decay and the two bias corrections 1 - beta^step.
+ * All four pointers of a tensor are dense device arrays of `numel` floats, 16-byte aligned. */
+typedef struct gs4d_adamw_tensor {
+    float* param;
+    const float* grad;
+    float* exp_avg;
+    float* exp_avg_sq;
+    size_t numel;
+    double lr;                 /* scalars are doubles, as torch keeps them: 1 - lr*wd, lr / bc1, sqrt(bc2), 1 - beta are */
+    double weight_decay;       /* formed in double and rounded to float once, like torch's Python-scalar arithmetic   */
+    double bias_correction1;   /* 1 - beta1^step */
+    double bias_correction2;   /* 1 - beta2^step */
+} gs4d_adamw_tensor;
+
+int gs4d_adamw_step(int ntensors, const gs4d_adamw_tensor* tensors /* host array */, double beta1, double beta2,
+                    double eps, void* stream);
+
+/* HexPlane grid regularisers: scene/regulation.py:22-29 (compute_plane_smoothness) and
+ * scene/gaussian_model.py:632-706 (_plane_regulation, _time_regulation, _l1_regulation, _l2_regulation,
+ * compute_regulation).  A term is one plane (channels-last [H][W][C] memory of the reference's [1,C,H,W]
+ * tensor), a kind and a weight; loss[0] = sum_i weight_i * reg_kind_i(plane_i):
+ *   SMOOTHNESS  mean over all elements of (t[h+2] - 2 t[h+1] + t[h])^2   (second difference along H)
+ *   L1          mean |1 - t|
+ *   L2          mean (1 - t)^2
+ * The backward ADDS g_loss[0] * weight_i * d reg / d plane to term.grad (same layout as the plane).
+ * At most 32 terms per call; scratch: gs4d_plane_reg_scratch_bytes(). */
+#define GS4D_REG_SMOOTHNESS 0
+#define GS4D_REG_L1 1
+#define GS4D_REG_L2 2
+typedef struct gs4d_plane_reg_term {
+    const float* plane;
+    float* grad;              /* may be NULL for the forward */
+    int C, W, H;
+    int kind;
+    float weight;
+} gs4d_plane_reg_term;
+
+size_t gs4d_plane_reg_scratch_bytes(void);
+int gs4d_plane_reg_forward(int nterms, const gs4d_plane_reg_term* terms /* host array */, float* scratch, float* loss,
+                           void* stream);
+int gs4d_plane_reg_backward(int nterms, const gs4d_plane_reg_term* terms /* host array */, const float* g_loss,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif
