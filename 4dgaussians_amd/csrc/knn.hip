@@ -168,6 +168,201 @@ __global__ __launch_bounds__(256) void mean_dist_kernel(int P, int nboxes, const
     if (live) out[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// k-nearest-neighbour query (k <= 128) of the fork's rigidity regulariser.
+//
+// Behaviour matched: pointops2/src/knnquery/knnquery_cuda_kernel.cu:65-108 (one batch segment): for every
+// query the nsample smallest squared distances over ALL points, ascending, slots beyond the point count left at
+// (1e10, first index).  Which of several points at EXACTLY the k-th distance the reference keeps depends on its
+// heap's history (a tied point is dropped when it happens to be the root); here the lower indices are kept.  The reference is a brute force
+// O(m * n) scan with a 100-entry per-thread heap in local memory.
+//
+// gfx950 design: the points are Morton-sorted once (same machinery as distCUDA2) into boxes of 64 with an
+// AABB each and super-boxes of 64 boxes.  One wave64 answers one query: candidates are 64-bit keys
+// (d2 bits << 32 | index) -- unique, and their integer order IS the reference's (distance, index) order --
+// collected in a 256-entry LDS buffer; when the buffer fills, a radix select over ballots finds the k-th
+// smallest key, which becomes the acceptance bound tau.  A box is scanned only if its AABB distance (a
+// lower bound of every member's distance in the same float arithmetic, see box_dist2) is <= tau's distance,
+// one point per lane, appended through a ballot-prefix compaction.  Queries are processed in Morton order so
+// neighbouring waves touch the same boxes.  Exact: bit-identical distances, identical indices up to that tie.
+#define KQ_BOX 64
+#define KQ_CAP 256
+#define KQ_MAXK 128
+typedef unsigned long long u64;
+
+__global__ __launch_bounds__(KQ_BOX) void kq_gather_box_kernel(int n, const float* __restrict__ pts,
+                                                               const uint32_t* __restrict__ order,
+                                                               float4* __restrict__ sorted, Box* __restrict__ boxes)
+{
+    const int i = blockIdx.x * KQ_BOX + threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (i < n) {
+        const uint32_t id = order[i];
+        const float p[3] = {pts[3 * (size_t)id], pts[3 * (size_t)id + 1], pts[3 * (size_t)id + 2]};
+        sorted[i] = make_float4(p[0], p[1], p[2], __uint_as_float(id));
+#pragma unroll
+        for (int a = 0; a < 3; a++) mn[a] = mx[a] = p[a];
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { boxes[blockIdx.x].mn[a] = mn[a]; boxes[blockIdx.x].mx[a] = mx[a]; }
+    }
+}
+
+__global__ __launch_bounds__(64) void kq_super_box_kernel(int nboxes, const Box* __restrict__ boxes, Box* __restrict__ supers)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    if (b < nboxes) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { mn[a] = boxes[b].mn[a]; mx[a] = boxes[b].mx[a]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { supers[blockIdx.x].mn[a] = mn[a]; supers[blockIdx.x].mx[a] = mx[a]; }
+    }
+}
+
+// One wave per query, four queries per workgroup (no workgroup barriers: the waves run independently).
+__global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int nboxes, int nsuper, int idbits,
+                                                       const float4* __restrict__ sorted, const Box* __restrict__ boxes,
+                                                       const Box* __restrict__ supers, const float* __restrict__ queries,
+                                                       const uint32_t* __restrict__ qorder,   // Morton order of the queries when they ARE the points, else NULL
+                                                       int* __restrict__ idx_out, float* __restrict__ d2_out)
+{
+    __shared__ u64 s_keys[4][KQ_CAP];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int qslot = blockIdx.x * 4 + wave;
+    if (qslot >= m) return;
+    const int q = qorder ? (int)qorder[qslot] : qslot;
+    const float qx = queries[3 * (size_t)q], qy = queries[3 * (size_t)q + 1], qz = queries[3 * (size_t)q + 2];
+    const float4 qp = make_float4(qx, qy, qz, 0.f);
+    u64* keys = s_keys[wave];
+    const u64 lt = (1ull << lane) - 1ull;
+    int cnt = 0;
+    u64 tau = ~0ull;               // accept key < tau
+    float tau_d2 = FLT_MAX;        // scan a box only if its AABB distance is <= tau_d2
+
+    // k-th smallest (1-based kk <= cnt) of the cnt keys: radix select over ballots, most significant bit first.
+    // Bit 63 (sign of d2) is always 0 and bits [idbits, 32) of the index half are always 0.
+    auto shrink = [&](int kk) {
+        __builtin_amdgcn_wave_barrier();
+        u64 my[4]; bool ok[4];
+#pragma unroll
+        for (int s = 0; s < 4; s++) { const int i = lane + 64 * s; ok[s] = i < cnt; my[s] = ok[s] ? keys[i] : ~0ull; }
+        u64 prefix = 0ull, known = 0ull;
+        int need = kk;
+        for (int bit = 62; bit >= 0; bit--) {
+            const u64 b = 1ull << bit;
+            if (bit < 32 && bit >= idbits) { known |= b; continue; }
+            int c = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) c += __popcll(__ballot(ok[s] && ((my[s] & known) == prefix) && !(my[s] & b)));
+            if (need > c) { need -= c; prefix |= b; }
+            known |= b;
+        }
+        const u64 kth = prefix;
+        int base = 0;
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            const bool keep = ok[s] && my[s] <= kth;
+            const u64 mask = __ballot(keep);
+            if (keep) keys[base + __popcll(mask & lt)] = my[s];
+            base += __popcll(mask);
+        }
+        cnt = base;                // == kk: keys are unique
+        tau = kth + 1ull;
+        tau_d2 = __uint_as_float((uint32_t)(kth >> 32));
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    auto scan_box = [&](int b) {
+        const int j = b * KQ_BOX + lane;
+        const float4 p = sorted[min(j, n - 1)];
+        const float d2 = (qx - p.x) * (qx - p.x) + (qy - p.y) * (qy - p.y) + (qz - p.z) * (qz - p.z);
+        const u64 key = ((u64)__float_as_uint(d2) << 32) | (u64)__float_as_uint(p.w);
+        const bool keep = j < n && d2 < 1e10f && key < tau;
+        const u64 mask = __ballot(keep);
+        if (keep) keys[cnt + __popcll(mask & lt)] = key;
+        cnt += __popcll(mask);
+        if (cnt > KQ_CAP - KQ_BOX && cnt > k) shrink(k);
+    };
+
+    // seed: the boxes around the query's own place in the Morton order (or around the closest box)
+    int b0;
+    if (qorder) {
+        b0 = qslot / KQ_BOX;
+    } else {
+        float best = FLT_MAX; int bestb = 0;
+        for (int b = lane; b < nboxes; b += 64) {
+            const float d = box_dist2(boxes[b], qp);
+            if (d < best) { best = d; bestb = b; }
+        }
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(best, off, 64);
+            const int ob = __shfl_xor(bestb, off, 64);
+            if (od < best || (od == best && ob < bestb)) { best = od; bestb = ob; }
+        }
+        b0 = bestb;
+    }
+    const int nseed = (k + KQ_BOX - 1) / KQ_BOX + 2;
+    int s0 = max(0, b0 - nseed / 2), s1 = min(nboxes, s0 + nseed);
+    s0 = max(0, s1 - nseed);
+    for (int b = s0; b < s1; b++) scan_box(b);
+    if (cnt > k) shrink(k);
+
+    // every other box whose AABB can still hold a better candidate
+    for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
+        const int sb = sb0 + lane;
+        u64 shit = __ballot(sb < nsuper && !(box_dist2(supers[min(sb, nsuper - 1)], qp) > tau_d2));
+        while (shit) {
+            const int sl = __ffsll((long long)shit) - 1;
+            shit &= shit - 1ull;
+            const int b = (sb0 + sl) * 64 + lane;
+            u64 bhit = __ballot(b < nboxes && (b < s0 || b >= s1) && !(box_dist2(boxes[min(b, nboxes - 1)], qp) > tau_d2));
+            while (bhit) {
+                const int bl = __ffsll((long long)bhit) - 1;
+                bhit &= bhit - 1ull;
+                const int bb = (sb0 + sl) * 64 + bl;
+                // tau may have tightened since the ballot: re-test (uniform)
+                if (!(box_dist2(boxes[bb], qp) > tau_d2)) scan_box(bb);
+            }
+        }
+    }
+    if (cnt > k) shrink(k);
+    __builtin_amdgcn_wave_barrier();
+
+    // ascending order by counting ranks (keys are unique); unfilled slots keep (1e10, 0) as in the reference
+    u64 mine[2]; int rank[2];
+#pragma unroll
+    for (int s = 0; s < 2; s++) { const int i = lane + 64 * s; mine[s] = i < cnt ? keys[i] : ~0ull; rank[s] = 0; }
+    for (int j = 0; j < cnt; j++) {
+        const u64 o = keys[j];
+        rank[0] += o < mine[0];
+        rank[1] += o < mine[1];
+    }
+    int* io = idx_out + (size_t)q * k;
+    float* dout = d2_out + (size_t)q * k;
+#pragma unroll
+    for (int s = 0; s < 2; s++) {
+        const int i = lane + 64 * s;
+        if (i < cnt) { io[rank[s]] = (int)(uint32_t)mine[s]; dout[rank[s]] = __uint_as_float((uint32_t)(mine[s] >> 32)); }
+        else if (i < k) { io[i] = 0; dout[i] = 1e10f; }
+    }
+}
+
 }  // namespace
 
 extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float* points,
@@ -217,5 +412,60 @@ extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, 
     hipLaunchKernelGGL(gather_box_kernel, dim3(nboxes), dim3(KNN_BOX), 0, s, P, points, vtmp[where], sorted, boxes);
     hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, nboxes, sorted, boxes, mean_dist2);
     GS4D_LAUNCH_CHECK("knn_mean_dist", 0, s);
+    return GS4D_OK;
+}
+
+extern "C" int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,
+                              int nsample, int* idx, float* dist2, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (m == 0) return GS4D_OK;
+    if (n <= 0 || m < 0 || !xyz || !idx || !dist2 || !alloc || nsample < 1 || nsample > KQ_MAXK) {
+        gs4d_set_error("gs4d_knn_query: bad arguments (need n >= 1, 1 <= nsample <= %d)", KQ_MAXK);
+        return GS4D_EINVAL;
+    }
+    GS4D_PROF("knn_query", s);
+    const bool same = new_xyz == nullptr || new_xyz == xyz;
+    const int nboxes = (n + KQ_BOX - 1) / KQ_BOX, nsuper = (nboxes + 63) / 64;
+    const int nred = min(1024, (n + 255) / 256);
+    char* p = nullptr;
+    float* partial; float* bbox; uint64_t* codes; uint32_t* ids; uint64_t* ktmp[2]; uint32_t* vtmp[2]; uint32_t* hist;
+    float4* sorted; Box* boxes; Box* supers;
+    auto carve = [&](char* base) {
+        p = base;
+        gs4d_obtain(p, partial, (size_t)nred * 6);
+        gs4d_obtain(p, bbox, 8);
+        gs4d_obtain(p, codes, (size_t)n);
+        gs4d_obtain(p, ids, (size_t)n);
+        gs4d_obtain(p, ktmp[0], (size_t)n);
+        gs4d_obtain(p, ktmp[1], (size_t)n);
+        gs4d_obtain(p, vtmp[0], (size_t)n);
+        gs4d_obtain(p, vtmp[1], (size_t)n);
+        gs4d_obtain(p, hist, (size_t)256 * gs4d_sort_blocks((size_t)n) + 256);
+        gs4d_obtain(p, sorted, (size_t)n);
+        gs4d_obtain(p, boxes, (size_t)nboxes);
+        gs4d_obtain(p, supers, (size_t)nsuper);
+    };
+    carve(nullptr);
+    const size_t bytes = (size_t)p + 256;
+    char* base = (char*)alloc(alloc_ctx, bytes);
+    if (!base) { gs4d_set_error("knn scratch allocator returned NULL"); return GS4D_EALLOC; }
+    if ((uintptr_t)base & 255) { gs4d_set_error("knn scratch must be 256-byte aligned"); return GS4D_EINVAL; }
+    carve(base);
+
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nred), dim3(256), 0, s, n, xyz, partial);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, s, nred, partial, bbox);
+    hipLaunchKernelGGL(morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, xyz, bbox, codes, ids);
+    GS4D_LAUNCH_CHECK("knn_query_morton", 0, s);
+    int where = 0;
+    int rc = gs4d_radix_sort_pairs((uint32_t)n, 4, codes, ids, ktmp, vtmp, hist, &where, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kq_gather_box_kernel, dim3(nboxes), dim3(KQ_BOX), 0, s, n, xyz, vtmp[where], sorted, boxes);
+    hipLaunchKernelGGL(kq_super_box_kernel, dim3(nsuper), dim3(64), 0, s, nboxes, boxes, supers);
+    int idbits = 1;
+    while (idbits < 32 && ((unsigned)(n - 1) >> idbits)) idbits++;
+    hipLaunchKernelGGL(kq_query_kernel, dim3((m + 3) / 4), dim3(256), 0, s, n, m, nsample, nboxes, nsuper, idbits, sorted,
+                       boxes, supers, same ? xyz : new_xyz, same ? vtmp[where] : (const uint32_t*)nullptr, idx, dist2);
+    GS4D_LAUNCH_CHECK("knn_query", 0, s);
     return GS4D_OK;
 }

@@ -1,0 +1,73 @@
+"""k-nearest-neighbour query over libgs4d.so (csrc/knn.hip): the counterpart of the one pointops2 operator the
+fork uses -- `knnquery` (pointops2/functions/pointops.py:34-49 over pointops2/src/knnquery/*) -- and of its
+caller `knn` (utils/general_utils.py:144-158), which feeds the k = 100 rigidity regulariser
+(gaussian_renderer/renderer.py:160-168,191-203).  Same names, arguments and return values.
+There is no CPU path (a missing library or CPU tensors raise).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _cabi
+
+
+def knnquery(nsample, xyz, new_xyz, offset, new_offset):
+    """input: xyz (n, 3), new_xyz (m, 3) or None, offset (b) / new_offset (b): cumulative batch ends.
+    output: idx int32 (m, nsample) -- indices into xyz --, dist float32 (m, nsample) = sqrt(dist2), ascending."""
+    if new_xyz is None:
+        new_xyz = xyz
+    if xyz.device.type != "cuda" or new_xyz.device.type != "cuda":
+        raise RuntimeError("knnquery needs tensors on a HIP device; there is no CPU path")
+    if xyz.dtype != torch.float32 or xyz.dim() != 2 or xyz.size(1) != 3 or new_xyz.dtype != torch.float32 or \
+            new_xyz.dim() != 2 or new_xyz.size(1) != 3:
+        raise RuntimeError("knnquery: xyz and new_xyz must be float32 tensors of shape (n, 3)")
+    assert xyz.is_contiguous() and new_xyz.is_contiguous()          # as the reference asserts
+    if not 1 <= int(nsample) <= 128:
+        raise RuntimeError("knnquery: nsample must be in 1..128")
+    L = _cabi.lib()
+    dev = xyz.device
+    m = new_xyz.shape[0]
+    idx = torch.zeros((m, nsample), dtype=torch.int32, device=dev)
+    dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=dev)
+    ends = [int(v) for v in offset.tolist()]
+    qends = [int(v) for v in new_offset.tolist()]
+    same = new_xyz is xyz or (new_xyz.data_ptr() == xyz.data_ptr() and new_xyz.shape == xyz.shape)
+    start = qstart = 0
+    for end, qend in zip(ends, qends):
+        n_b, m_b = end - start, qend - qstart
+        if m_b > 0:
+            if n_b <= 0:
+                raise RuntimeError("knnquery: a batch with queries has no points")
+            pts = xyz[start:end]
+            qs = new_xyz[qstart:qend]
+            scratch = _cabi.TensorAllocator(dev)
+            with torch.cuda.device(dev):
+                rc = L.gs4d_knn_query(scratch.callback, scratch.ctx, C.c_int(n_b), _cabi.ptr(pts), C.c_int(m_b),
+                                      C.c_void_p(0) if (same and start == qstart) else _cabi.ptr(qs), C.c_int(int(nsample)),
+                                      C.c_void_p(idx.data_ptr() + 4 * qstart * nsample),
+                                      C.c_void_p(dist2.data_ptr() + 4 * qstart * nsample), _cabi.current_stream(dev))
+            scratch.close()
+            _cabi.check(rc, "gs4d_knn_query")
+            if start:
+                idx[qstart:qend] += start                     # the reference's indices are global (into xyz)
+        start, qstart = end, qend
+    return idx, torch.sqrt(dist2)
+
+
+def knn(x, src, k, transpose=False):
+    """utils/general_utils.py:144-158: x (b, n, 3), src (b, m, 3) -> idx int64 (b, n, k) into src, dists (b, n, k)."""
+    if transpose:
+        x = x.transpose(1, 2).contiguous()
+        src = src.transpose(1, 2).contiguous()
+    b, n, _ = x.shape
+    m = src.shape[1]
+    same = x.data_ptr() == src.data_ptr() and x.shape == src.shape
+    x = x.reshape(-1, 3)
+    src = x if same else src.reshape(-1, 3)
+    x_offset = torch.cumsum(torch.full((b,), n, dtype=torch.long), dim=0).int()
+    src_offset = torch.cumsum(torch.full((b,), m, dtype=torch.long), dim=0).int()
+    idx, dists = knnquery(k, src, x, src_offset, x_offset)
+    idx = idx.view(b, n, k) - (src_offset - m).to(idx.device)[:, None, None]
+    return idx.long(), dists.view(b, n, k)

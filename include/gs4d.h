@@ -167,6 +167,18 @@ int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float
                         void* stream);
 
 /*
+ * k-nearest-neighbour query of the fork's rigidity regulariser.  Replaces
+ * knnquery_cuda for ONE batch segment: pointops2/src/knnquery/knnquery_cuda_kernel.cu:65-108 (launcher :111-116,
+ * Python KNNQuery pointops2/functions/pointops.py:34-49, caller utils/general_utils.py:144-158).
+ * xyz [n,3], new_xyz [m,3] (NULL = query the points themselves) -> idx int32 [m,nsample] (indices into xyz),
+ * dist2 [m,nsample] squared distances, ascending; among points at exactly the k-th distance the lower indices are
+ * kept (the reference's choice there depends on its heap's history); if n < nsample the remaining slots hold
+ * (index 0, 1e10) as the reference leaves them.  1 <= nsample <= 128.  Distances are exact.
+ */
+int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,
+                   int nsample, int* idx, float* dist2, void* stream);
+
+/*
  * HexPlane deformation field.  The reference implements it in PyTorch
  * (scene/hexplane.py:100-131,192-215 gathers; scene/deformation.py:128-200,265-298 trunk, heads,
  * positional encodings; utils/graphics_utils.py:110-133 quaternion update), so there is no native

@@ -35,3 +35,15 @@ def morton(points: np.ndarray):
     lib().gs4d_ref_knn_morton(P, pts.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p),
                               codes.ctypes.data_as(C.c_void_p), order.ctypes.data_as(C.c_void_p))
     return out, codes, order
+
+
+def knn_query(xyz: np.ndarray, new_xyz: np.ndarray, nsample: int):
+    """knnquery_cuda_kernel (one batch segment): -> (idx int32 [m, nsample], dist2 float32 [m, nsample])."""
+    assert 1 <= nsample <= 100
+    a = np.ascontiguousarray(xyz, np.float32)
+    b = np.ascontiguousarray(new_xyz, np.float32)
+    idx = np.zeros((b.shape[0], nsample), np.int32)
+    d2 = np.zeros((b.shape[0], nsample), np.float32)
+    lib().gs4d_ref_knn_query(a.shape[0], a.ctypes.data_as(C.c_void_p), b.shape[0], b.ctypes.data_as(C.c_void_p),
+                             nsample, idx.ctypes.data_as(C.c_void_p), d2.ctypes.data_as(C.c_void_p))
+    return idx, d2

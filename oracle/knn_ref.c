@@ -165,3 +165,51 @@ void gs4d_ref_knn_morton(int P, const float* points, float* out, uint32_t* codes
 	}
 	free(codes); free(idx); free(codes2); free(idx2); free(boxes);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * k-nearest-neighbour query of the fork's rigidity regulariser: a literal
+ * restatement of pointops2/src/knnquery/knnquery_cuda_kernel.cu:5-108 for ONE batch segment
+ * (start = 0, end = n): per query a max-heap of nsample (<= 100) candidates seeded with
+ * (1e10, start), strict `d2 < root` replacement in ascending point order, then the in-place heap sort
+ * (:38-47), which leaves the distances ascending (which of several equal-distance points survives at
+ * the k-th place depends on the heap's history).
+ * PARITY UNPINNED against the reference binary (CUDA, unbuildable here); the reference has no test
+ * for this operator.  Pinned by a numpy brute force in tests/test_oracle_knn.py.
+ * ------------------------------------------------------------------------------------------------ */
+static void kq_reheap(float* dist, int* idx, int k) /* knnquery_cuda_kernel.cu:21-36 */
+{
+    int root = 0, child = 1;
+    while (child < k) {
+        if (child + 1 < k && dist[child + 1] > dist[child]) child++;
+        if (dist[root] > dist[child]) return;
+        float td = dist[root]; dist[root] = dist[child]; dist[child] = td;
+        int ti = idx[root]; idx[root] = idx[child]; idx[child] = ti;
+        root = child;
+        child = root * 2 + 1;
+    }
+}
+
+void gs4d_ref_knn_query(int n, const float* xyz, int m, const float* new_xyz, int nsample, int* idx, float* dist2)
+{
+    for (int q = 0; q < m; q++) { /* knnquery_cuda_kernel.cu:65-108, one thread per query */
+        float best_dist[100];
+        int best_idx[100];
+        const float nx = new_xyz[3 * q], ny = new_xyz[3 * q + 1], nz = new_xyz[3 * q + 2];
+        for (int i = 0; i < nsample; i++) { best_dist[i] = 1e10f; best_idx[i] = 0; }
+        for (int i = 0; i < n; i++) {
+            const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+            const float d2 = (nx - x) * (nx - x) + (ny - y) * (ny - y) + (nz - z) * (nz - z);
+            if (d2 < best_dist[0]) {
+                best_dist[0] = d2;
+                best_idx[0] = i;
+                kq_reheap(best_dist, best_idx, nsample);
+            }
+        }
+        for (int i = nsample - 1; i > 0; i--) { /* heap_sort, :38-47 */
+            float td = best_dist[0]; best_dist[0] = best_dist[i]; best_dist[i] = td;
+            int ti = best_idx[0]; best_idx[0] = best_idx[i]; best_idx[i] = ti;
+            kq_reheap(best_dist, best_idx, i);
+        }
+        for (int i = 0; i < nsample; i++) { idx[(size_t)q * nsample + i] = best_idx[i]; dist2[(size_t)q * nsample + i] = best_dist[i]; }
+    }
+}
