@@ -690,6 +690,9 @@ struct GemmJob {
     const float* bias; int N;
     float* Y; int ldy; int ycol0;
     const float* mask; int ldm; int mcol0;         // optional: multiply by (mask > 0)
+    // FUSE variant (N == 64): Y2[rows, y2col0 + j] = relu(Y) W2^T + bias2, j < N2 <= 64, W2 = nn.Linear weight [N2][64];
+    // Y itself is stored only if store_y
+    const float* W2; const float* bias2; int N2; float* Y2; int ldy2; int y2col0; int store_y;
 };
 struct GemmJobs { GemmJob j[8]; int wg_begin[9]; };   // job i owns workgroups [wg_begin[i], wg_begin[i+1])
 
@@ -717,7 +720,13 @@ static inline __host__ __device__ int gemm_kp(const GemmJob& J)
 // always multiplied (columns >= N are zero in LDS).
 // Measured (C2, rocprofv3): every launch moves 2.2-3.6 TB/s of its own operands -- these layer-by-layer
 // products are bound by HBM traffic, not by the matrix cores (MFMA busy ~46 %).
-template <bool RELU, bool MASK>
+// FUSE: a head's two Linears in one pass over the rows.  The first layer's 32 x 64 accumulator tile of a wave is
+// biased, (optionally stored,) rectified and transposed through a small per-wave LDS tile -- 32 columns at a
+// time -- into the A-operand layout, multiplied with the second weight matrix (resident in LDS next to the
+// first), and only the second layer's <= 64 outputs per row are written: the 256-float H1 row is not re-read
+// (and, without a backward to feed, not even written).
+#define FUSE_TP 36          // row pitch of the transpose tile (floats)
+template <bool RELU, bool MASK, bool FUSE>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 {
     extern __shared__ float smem[];
@@ -731,7 +740,15 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
     const int Kb = Kp >> 3;
     const int N = J.N;
     float* sB = smem;                                   // [Kb][2 (k half)][64 (column)][4 (k)]
+    float* sB2 = sB + Kp * 64;                          // FUSE: [8][2][64][4]
+    float* sT = sB2 + 64 * 64;                          // FUSE: [4 waves][32][FUSE_TP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (FUSE) {                                         // B2[k][j] = W2[j][k], zero for j >= N2
+        for (int e = tid; e < 64 * 64; e += 256) {
+            const int j = e >> 6, k = e & 63;
+            sB2[(((k >> 3) * 2 + ((k >> 2) & 1)) * 64 + j) * 4 + (k & 3)] = j < J.N2 ? J.W2[(size_t)j * 64 + k] : 0.f;
+        }
+    }
 
     // ---- stage B (zero rows for A's padding columns) and the A column of every K block.  All of a thread's
     // loads are issued before its first LDS store, so staging costs about one memory round trip.
@@ -816,7 +833,51 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv1[q], acc1, 0, 0, 0);
             }
         }
-        if (g == NG - 1) {
+        if (g == NG - 1 && FUSE) {
+            const int row0 = rb * ROWS_PER_WG + wave * 32 + 4 * khalf;
+            float* Tw = sT + wave * (32 * FUSE_TP);
+            const float4* sB24 = reinterpret_cast<const float4*>(sB2) + khalf * 64 + col;
+            f32x16 c0 = {0}, c1 = {0};
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const float bias = half ? bias1 : bias0;
+                __builtin_amdgcn_wave_barrier();            // the previous half's readers are done (same wave)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rl = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    const float v = (half ? acc1[r] : acc0[r]) + bias;
+                    if (J.store_y && row0 - 4 * khalf + rl < P) Y[(size_t)(row0 - 4 * khalf + rl) * ldy + col + 32 * half] = v;
+                    Tw[rl * FUSE_TP + col] = fmaxf(v, 0.f);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    const float4 a4 = *reinterpret_cast<const float4*>(Tw + i * FUSE_TP + 8 * m + 4 * khalf);
+                    const float4 b0 = sB24[(half * 4 + m) * 128], b1 = sB24[(half * 4 + m) * 128 + 32];
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+                    const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv0[q], c0, 0, 0, 0);
+                        if (J.N2 > 32) c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv1[q], c1, 0, 0, 0);
+                    }
+                }
+            }
+            const int N2 = J.N2;
+            const float b20 = col < N2 ? J.bias2[col] : 0.f, b21 = col + 32 < N2 ? J.bias2[col + 32] : 0.f;
+            float* __restrict__ Y2 = J.Y2 + J.y2col0;
+            const int ldy2 = J.ldy2;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                if (row >= P) continue;
+                if (col < N2) Y2[(size_t)row * ldy2 + col] = c0[r] + b20;
+                if (col + 32 < N2) Y2[(size_t)row * ldy2 + col + 32] = c1[r] + b21;
+            }
+            acc0 = (f32x16){0};
+            acc1 = (f32x16){0};
+        }
+        if (g == NG - 1 && !FUSE) {
             // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
             // All mask loads are issued before the first store.
             const int row0 = rb * ROWS_PER_WG + wave * 32 + 4 * khalf;
@@ -1257,27 +1318,38 @@ static int launch_gemm(int P, GemmJobs& jobs, int njobs, hipStream_t s)
         for (int sg = 0; sg < j.a_nseg; sg++) ok = ok && (j.a_beg[sg] & 3) == 0 && j.a_beg[sg] + pad8(j.a_len[sg]) <= j.lda;
         if (!ok) { gs4d_set_error("deform gemm: operand %d violates the 16-byte / pad-8 layout rules", i); return GS4D_EINVAL; }
     }
-    const size_t lds = gemm_lds_bytes(Kpmax);
-    // RELU and MASK are per-launch properties (every job of a launch agrees)
-    const bool relu = jobs.j[0].relu_a != 0, mask = jobs.j[0].mask != nullptr;
-    for (int i = 1; i < njobs; i++)
-        if ((jobs.j[i].relu_a != 0) != relu || (jobs.j[i].mask != nullptr) != mask) {
-            gs4d_set_error("deform gemm: jobs of one launch must agree on ReLU and mask");
+    // RELU, MASK and FUSE are per-launch properties (every job of a launch agrees)
+    const bool relu = jobs.j[0].relu_a != 0, mask = jobs.j[0].mask != nullptr, fuse = jobs.j[0].W2 != nullptr;
+    for (int i = 0; i < njobs; i++) {
+        const GemmJob& j = jobs.j[i];
+        if ((j.relu_a != 0) != relu || (j.mask != nullptr) != mask || (j.W2 != nullptr) != fuse) {
+            gs4d_set_error("deform gemm: jobs of one launch must agree on ReLU, mask and fusion");
             return GS4D_EINVAL;
         }
-    void (*kern)(int, GemmJobs) = relu ? (mask ? gemm_rows_kernel<true, true> : gemm_rows_kernel<true, false>)
-                                       : (mask ? gemm_rows_kernel<false, true> : gemm_rows_kernel<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
-    if (!attr_set[relu * 2 + mask]) {
+        if (fuse && (!relu || mask || j.N != WIDTH || !j.bias2 || !j.Y2 || j.N2 < 1 || j.N2 > 64)) {
+            gs4d_set_error("deform gemm: bad fused job %d", i);
+            return GS4D_EINVAL;
+        }
+    }
+    const size_t lds = gemm_lds_bytes(Kpmax) + (fuse ? sizeof(float) * (64 * 64 + 4 * 32 * FUSE_TP) : 0);
+    void (*kern)(int, GemmJobs) = fuse ? gemm_rows_kernel<true, false, true>
+                                  : relu ? (mask ? gemm_rows_kernel<true, true, false> : gemm_rows_kernel<true, false, false>)
+                                         : (mask ? gemm_rows_kernel<false, true, false> : gemm_rows_kernel<false, false, false>);
+    static bool attr_set[5] = {false, false, false, false, false};
+    const int variant = fuse ? 4 : relu * 2 + mask;
+    if (!attr_set[variant]) {
         GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512));
-        attr_set[relu * 2 + mask] = true;
+        attr_set[variant] = true;
     }
     // persistent 1-D grid, ~4 workgroups per CU in total (mild oversubscription measured faster than an exactly
     // resident grid), shared between the jobs in proportion to their MFMA work per row block
     const int nrb = (P + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int total = GEMM_CUS * 4;
     double wsum = 0, w[8];
-    for (int i = 0; i < njobs; i++) { w[i] = (gemm_kp(jobs.j[i]) / 8) * 2 + 6; wsum += w[i]; }
+    for (int i = 0; i < njobs; i++) {
+        w[i] = (gemm_kp(jobs.j[i]) / 8) * 2 + 6 + (fuse ? 8 * (jobs.j[i].N2 > 32 ? 2 : 1) + 4 : 0);
+        wsum += w[i];
+    }
     jobs.wg_begin[0] = 0;
     for (int i = 0; i < 8; i++) {
         int n = 0;
@@ -1408,7 +1480,8 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
         rc = launch_gemm(P, jobs, 1, s);
         if (rc) return rc;
     }
-    // heads, first Linear: H1[:, h*64 .. ] = relu([hidden | pe_h | tf]) W1_h^T + b1_h
+    // heads, both Linears in one pass: H1_h = relu([hidden | pe_h | tf]) W1_h^T + b1_h (stored only when a backward
+    // will read it), O[:, ocol_h ..] = relu(H1_h) W2_h^T + b2_h
     {
         GemmJobs jobs = {};
         for (int h = 0; h < NHEAD; h++) {
@@ -1419,16 +1492,10 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
             j.a_beg[j.a_nseg] = 0; j.a_len[j.a_nseg++] = WIDTH;
             if (l.head_seglen[h] > 0) { j.a_beg[j.a_nseg] = l.head_seg[h]; j.a_len[j.a_nseg++] = l.head_seglen[h]; }
             j.a_beg[j.a_nseg] = l.oT; j.a_len[j.a_nseg++] = l.e;
+            j.W2 = d->head_w2[h]; j.bias2 = d->head_b2[h]; j.N2 = l.head_out[h];
+            j.Y2 = w.O; j.ldy2 = OUT_LD; j.y2col0 = l.head_ocol[h];
+            j.store_y = d->no_grad ? 0 : 1;
         }
-        rc = launch_gemm(P, jobs, NHEAD, s);
-        if (rc) return rc;
-    }
-    // heads, second Linear: O[:, ocol_h .. ] = relu(H1_h) W2_h^T + b2_h
-    {
-        GemmJobs jobs = {};
-        for (int h = 0; h < NHEAD; h++)
-            jobs.j[h] = simple_job(w.H1, NHEAD * WIDTH, h * WIDTH, WIDTH, 1, d->head_w2[h], WIDTH, 0, 1, d->head_b2[h],
-                                   l.head_out[h], w.O, OUT_LD, l.head_ocol[h]);
         rc = launch_gemm(P, jobs, NHEAD, s);
         if (rc) return rc;
     }

@@ -32,7 +32,7 @@ class DeformDesc(C.Structure):
                 ("planes", FP * (MAX_LEVELS * 6)), ("plane_w", C.c_int * (MAX_LEVELS * 6)),
                 ("plane_h", C.c_int * (MAX_LEVELS * 6)), ("aabb", FP), ("ft_w", FP), ("ft_b", FP),
                 ("trunk_w", FP * MAX_TRUNK), ("trunk_b", FP * MAX_TRUNK), ("head_w1", FP * 4), ("head_b1", FP * 4),
-                ("head_w2", FP * 4), ("head_b2", FP * 4)]
+                ("head_w2", FP * 4), ("head_b2", FP * 4), ("no_grad", C.c_int)]
 
 
 class DeformGrads(C.Structure):
@@ -105,6 +105,7 @@ class _DeformFunction(torch.autograd.Function):
             shs_ = shs_.clone()
         planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
         d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
+        d.no_grad = 0 if any(ctx.needs_input_grad) else 1      # under torch.no_grad() nothing will read the activations
         o_xyz, o_sc, o_rot, o_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, shs_))
         ws = torch.empty(max(int(L.gs4d_deform_workspace_bytes(C.byref(d), C.c_int(P))), 256), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):

@@ -212,6 +212,8 @@ typedef struct gs4d_deform_desc {
     const float* head_b1[4];
     const float* head_w2[4];  /* second Linear [out_h][64], out = 3,3,4,48 */
     const float* head_b2[4];
+    int no_grad;              /* 1: no backward will follow (render_for_image): the forward skips the activations only the
+                                 backward reads (the workspace then cannot be passed to gs4d_deform_backward) */
 } gs4d_deform_desc;
 
 /* Gradient destinations, same shapes as the parameters above; every one must be zero-initialised
