@@ -56,7 +56,9 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
         scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
         sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=debug)
     rasterizer = GaussianRasterizer(raster_settings=settings)
-    means3D, opacity, shs, scales, rotations = pc._xyz, pc._opacity, pc._features, pc._scaling, pc._rotation
+    # GaussianParams keeps one (P,16,3) tensor; a GaussianModel concatenates f_dc and f_rest (get_features, :143-146)
+    shs = pc._features if hasattr(pc, "_features") else pc.get_features
+    means3D, opacity, scales, rotations = pc._xyz, pc._opacity, pc._scaling, pc._rotation
     if "coarse" not in stage and deform is not None:
         n = means3D.shape[0]
         time = torch.full((n, 1), cam.time, dtype=torch.float32, device=means3D.device)
@@ -72,3 +74,17 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
 @torch.no_grad()
 def render_for_image(cam: Camera, pc: GaussianParams, deform, bg_color, scaling_modifier=1.0, stage="fine"):
     return render(cam, pc, deform, bg_color, scaling_modifier, stage)[0]
+
+
+def render_set_fps(views, pc, deform, bg_color, stage="fine"):
+    """The FPS loop of render.py:58-77: frames / (t_end - t_after_first_frame), each frame converted to 8 bit and
+    copied to the host as the reference's to8b does (:64).  -> (fps, list of uint8 HxWx3 numpy frames)."""
+    import time
+    frames, t1 = [], None
+    for idx, view in enumerate(views):
+        if idx == 0:
+            t1 = time.time()          # the reference starts its clock before the first frame's render call...
+        img = render_for_image(view, pc, deform, bg_color, stage=stage)
+        frames.append((255 * torch.clamp(img, 0, 1)).to(torch.uint8).permute(1, 2, 0).cpu().numpy())
+    t2 = time.time()
+    return (len(views) - 1) / max(t2 - t1, 1e-9), frames

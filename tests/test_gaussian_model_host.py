@@ -1,0 +1,175 @@
+"""Host-side logic of 4dgaussians_amd/scene/gaussian_model.py on the CPU: the PLY
+layout and round trip, the checkpoint tuple, the learning-rate schedule, and the optimizer-state surgery of
+densify / clone / split / prune, with torch.optim.AdamW injected in place of the fused optimizer (the surgery
+only touches `param_groups` and `state`, which FusedAdamW shares with it)."""
+import types
+
+import numpy as np
+import torch
+
+from conftest import pkg
+from test_gpu_deformation import make_args
+from oracle import deformation_ref as R
+
+GM = pkg("scene.gaussian_model")
+
+
+def opt_args():
+    return types.SimpleNamespace(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016,
+                                 position_lr_delay_mult=0.01, position_lr_max_steps=20000, deformation_lr_init=0.00016,
+                                 deformation_lr_final=0.000016, deformation_lr_delay_mult=0.01, grid_lr_init=0.0016,
+                                 grid_lr_final=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+
+
+def model(n=50, seed=0):
+    cfg = R.DeformConfig(plane_channels=8, resolution=[4, 4, 4, 3], multires=[1])
+    torch.manual_seed(seed)
+    m = GM.GaussianModel(3, make_args(cfg), device="cpu", optimizer_cls=torch.optim.AdamW)
+    g = torch.Generator().manual_seed(seed)
+    P = lambda *s: torch.nn.Parameter(torch.randn(*s, generator=g))
+    m._xyz, m._features_dc, m._features_rest = P(n, 3), P(n, 1, 3), P(n, 15, 3)
+    m._opacity, m._scaling, m._rotation = P(n, 1), torch.nn.Parameter(torch.randn(n, 3, generator=g) * 0.3 - 2), P(n, 4)
+    m._deformation_table = torch.ones(n, dtype=torch.bool)
+    m.max_radii2D = torch.zeros(n)
+    m.spatial_lr_scale = 5.0
+    m.training_setup(opt_args())
+    return m
+
+
+def step(m):
+    for grp in m.optimizer.param_groups:
+        for p in grp["params"]:
+            if p.requires_grad and p.dim() and "grid" not in grp["name"] and grp["name"] != "deformation":
+                p.grad = torch.ones_like(p)
+    m.optimizer.step()
+    m.optimizer.zero_grad(set_to_none=True)
+
+
+def test_ply_layout_and_round_trip(tmp_path):
+    m = model(37)
+    path = str(tmp_path / "point_cloud" / "iteration_10" / "point_cloud.ply")
+    m.save_ply(path)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[:3] == ["ply", "format binary_little_endian 1.0", "element vertex 37"]
+    names = [l.split()[2] for l in lines[3:]]
+    assert all(l.startswith("property float ") for l in lines[3:])
+    # scene/gaussian_model.py:244-256: x,y,z,nx,ny,nz, 3 f_dc, 45 f_rest, opacity, 3 scales, 4 rotations = 62 floats
+    assert names == ["x", "y", "z", "nx", "ny", "nz"] + [f"f_dc_{i}" for i in range(3)] + [f"f_rest_{i}" for i in range(45)] + \
+        ["opacity"] + [f"scale_{i}" for i in range(3)] + [f"rot_{i}" for i in range(4)]
+    table = np.frombuffer(body, "<f4").reshape(37, 62)
+    np.testing.assert_array_equal(table[:, :3], m._xyz.detach().numpy())
+    assert (table[:, 3:6] == 0).all()
+    # f_rest is stored channel-major: (P, 15, 3) -> transpose(1, 2) -> (P, 3, 15) -> flatten  (gaussian_model.py:285)
+    np.testing.assert_array_equal(table[:, 9:54], m._features_rest.detach().transpose(1, 2).flatten(1).numpy())
+    m2 = model(5, seed=1)
+    m2.load_ply(path)
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(m2, k).detach(), getattr(m, k).detach()), k
+        assert getattr(m2, k).requires_grad
+    assert m2.active_sh_degree == 3
+    # ascii PLY files (other writers) load too
+    apath = str(tmp_path / "a.ply")
+    with open(apath, "w") as f:
+        f.write("\n".join(lines[:1] + ["format ascii 1.0"] + lines[2:]) + "\nend_header\n")
+        np.savetxt(f, table, fmt="%.9g")
+    m3 = model(5, seed=2)
+    m3.load_ply(apath)
+    assert torch.allclose(m3._scaling.detach(), m._scaling.detach(), rtol=1e-6)
+
+
+def test_lr_schedule_and_groups():
+    m = model()
+    assert [g["name"] for g in m.optimizer.param_groups] == ["xyz", "deformation", "grid", "f_dc", "f_rest", "opacity", "scaling", "rotation"]
+    assert abs(m.optimizer.param_groups[0]["lr"] - 0.00016 * 5.0) < 1e-12 and m.optimizer.param_groups[4]["lr"] == 0.0025 / 20.0
+    m.update_learning_rate(10000)
+    want = np.exp(0.5 * np.log(0.00016 * 5) + 0.5 * np.log(0.0000016 * 5))       # delay_steps = 0 -> pure log-lerp
+    assert abs(m.optimizer.param_groups[0]["lr"] - want) < 1e-12
+    assert abs(m.optimizer.param_groups[2]["lr"] - np.exp(0.5 * np.log(0.0016 * 5) + 0.5 * np.log(0.00016 * 5))) < 1e-12
+    f = GM.get_expon_lr_func(1e-2, 1e-4, lr_delay_steps=100, lr_delay_mult=0.1, max_steps=1000)
+    assert abs(f(0) - 1e-3) < 1e-12 and abs(f(1000) - 1e-4) < 1e-12 and f(-1) == 0.0
+
+
+def test_prune_clone_split_keep_optimizer_state_aligned():
+    m = model(60)
+    step(m)
+    old = {g["name"]: (g["params"][0].detach().clone(), m.optimizer.state[g["params"][0]]["exp_avg"].clone())
+           for g in m.optimizer.param_groups if len(g["params"]) == 1}
+    mask = torch.zeros(60, dtype=torch.bool)
+    mask[::3] = True
+    m.prune_points(mask)
+    assert m.get_xyz.shape[0] == 40 and m.denom.shape == (40, 1) and m._deformation_table.shape == (40,)
+    for g in m.optimizer.param_groups:
+        if len(g["params"]) == 1:
+            p = g["params"][0]
+            assert torch.equal(p.detach(), old[g["name"]][0][~mask])
+            assert torch.equal(m.optimizer.state[p]["exp_avg"], old[g["name"]][1][~mask])
+            assert p is getattr(m, {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity",
+                                    "scaling": "_scaling", "rotation": "_rotation"}[g["name"]])
+    step(m)                                                        # state and parameters still line up
+
+    # clone: small Gaussians with a large accumulated gradient are duplicated, moments of the copies start at zero
+    n = m.get_xyz.shape[0]
+    grads = torch.zeros(n, 1)
+    grads[:5] = 1.0
+    m.percent_dense = 1e9                                          # everything counts as "small"
+    before = m._xyz.detach().clone()
+    m.densify_and_clone(grads, 0.5, 1.0)
+    assert m.get_xyz.shape[0] == n + 5
+    assert torch.equal(m._xyz.detach()[n:], before[:5])
+    assert float(m.optimizer.state[m._xyz]["exp_avg"][n:].abs().max()) == 0.0
+    assert m.xyz_gradient_accum.shape == (n + 5, 1) and float(m.xyz_gradient_accum.abs().max()) == 0.0
+
+    # split: large Gaussians are replaced by N = 2 samples with scales / (0.8 N)
+    n = m.get_xyz.shape[0]
+    m.percent_dense = 0.0                                          # everything counts as "large"
+    grads = torch.zeros(n, 1)
+    grads[3] = grads[7] = 1.0
+    s_before = m.get_scaling.detach().clone()
+    torch.manual_seed(0)
+    m.densify_and_split(grads, 0.5, 1.0)
+    assert m.get_xyz.shape[0] == n + 2 * 2 - 2
+    assert torch.allclose(m.get_scaling.detach()[-4:], torch.cat([s_before[[3, 7]], s_before[[3, 7]]]) / 1.6, rtol=1e-5)
+    step(m)
+
+    # prune by opacity / screen size / world size (gaussian_model.py:583-591)
+    n = m.get_xyz.shape[0]
+    with torch.no_grad():
+        m._opacity[:] = 3.0
+        m._opacity[0] = -10.0                                      # sigmoid -> ~0: below min_opacity
+        m._scaling[:] = -3.0
+        m._scaling[1, 0] = 2.0                                     # exp(2) > 0.1 * extent
+    m.max_radii2D = torch.zeros(n)
+    m.max_radii2D[2] = 100.0
+    m.prune(0.0, 0.005, 1.0, 40)
+    assert m.get_xyz.shape[0] == n - 3
+    m.reset_opacity()
+    assert float(m.get_opacity.max()) <= 0.01 + 1e-6 and m._opacity is m.optimizer.param_groups[5]["params"][0]
+    try:
+        m.grow()
+        assert False
+    except NotImplementedError:
+        pass
+
+
+def test_capture_restore_and_deformation_files(tmp_path):
+    m = model(20)
+    step(m)
+    ckpt = m.capture()
+    assert len(ckpt) == 14
+    torch.save((ckpt, 7), str(tmp_path / "chkpnt_fine_7.pth"))
+    (args_back, it) = torch.load(str(tmp_path / "chkpnt_fine_7.pth"), weights_only=False)   # our own file
+    m2 = model(3, seed=4)
+    m2.restore(args_back, opt_args())
+    assert it == 7 and torch.equal(m2._xyz.detach(), m._xyz.detach()) and m2.spatial_lr_scale == 5.0
+    assert torch.equal(m2.optimizer.state[m2._xyz]["exp_avg"], m.optimizer.state[m._xyz]["exp_avg"])
+    for (k, a), (_, b) in zip(m._deformation.state_dict().items(), m2._deformation.state_dict().items()):
+        assert torch.equal(a, b), k
+    m._deformation_accum = torch.rand(20, 3)
+    m.save_deformation(str(tmp_path / "pc"))
+    m3 = model(20, seed=9)
+    m3.load_model(str(tmp_path / "pc"))
+    assert torch.equal(m3._deformation_accum, m._deformation_accum)
+    for (k, a), (_, b) in zip(m._deformation.state_dict().items(), m3._deformation.state_dict().items()):
+        assert torch.equal(a, b), k
