@@ -112,7 +112,7 @@ def main():
     deform = deform.to(dev)
     if world > 1:  # replicas start identical
         for p in list(pc.parameters()) + list(deform.parameters()):
-            dist.broadcast(p.data, 0)
+            dist.broadcast(par._memory_order_view(p.data), 0)      # a contiguous 1-D view, also of channels-last planes
     # each rank looks at the scene from its own azimuth / timestamp (view-parallel)
     rng = np.random.default_rng(1234 + rank)
     cam_np = syn.look_at_camera(W, H, azimuth=0.7 + 0.6 * rank)
@@ -152,9 +152,9 @@ def main():
             pc._scaling.add_(float(off.item()) - log_s0_offset)
         log_s0_offset = float(off.item())
     raw = dict(raw, log_scales=(raw["log_scales"] + np.float32(log_s0_offset)).astype(np.float32))
-    gauss_bucket = par.GradBucket(pc.parameters())
-    deform_bucket = par.GradBucket(deform.parameters())
     all_params = list(pc.parameters()) + list(deform.parameters())
+    # ONE flat bucket for the Gaussian and the deformation gradients: one pack, one all-reduce per step
+    bucket = par.GradBucket(all_params)
 
     def train_step():
         image, *_ = R.render(cam, pc, deform, bg)
@@ -163,10 +163,7 @@ def main():
             loss = loss / world                           # SUM over ranks == mean over the global batch
         loss.backward()
         if world > 1:
-            gauss_bucket.all_reduce(async_op=True)        # overlaps with packing the second bucket
-            deform_bucket.all_reduce(async_op=True)
-            gauss_bucket.finish()
-            deform_bucket.finish()
+            bucket.all_reduce()
         for p in all_params:
             p.grad = None
 
@@ -287,7 +284,7 @@ def main():
                                    f"1 view per GPU per step", "global_batch_views": world,
                        "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
                        "log_s0_offset": round(log_s0_offset, 4),
-                       "grad_allreduce_bytes": gauss_bucket.nbytes + deform_bucket.nbytes},
+                       "grad_allreduce_bytes": bucket.nbytes},
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
@@ -314,10 +311,7 @@ def main():
                 loss = loss / world
             loss.backward()
             if world > 1:
-                gauss_bucket.all_reduce(async_op=True)
-                deform_bucket.all_reduce(async_op=True)
-                gauss_bucket.finish()
-                deform_bucket.finish()
+                bucket.all_reduce()
             opt.step()
             for p in all_params:
                 p.grad = None
