@@ -24,49 +24,95 @@ class GradBucket:
     Packing is one multi-tensor copy (torch._foreach_copy_) instead of one small copy kernel per parameter
     (~45 tensors: the launches cost more than the all-reduce itself), and nothing is copied back: after
     finish() every p.grad IS a view of the reduced bucket (slots start on 64-float boundaries so the views
-    keep the 16-byte alignment the fused optimizer needs; the padding travels as zeros)."""
+    keep the 16-byte alignment the fused optimizer needs; the padding travels as zeros).
+
+    Early parameters: a gradient that is final before the backward pass ends can start its all-reduce at once
+    and overlap with the rest of the backward.  The SH coefficients are the case that matters: the deformation
+    adds a residual to them (scene/deformation.py:191-197), so dL/d_features == dL/d(deformed shs), which
+    exists as soon as the rasterizer's backward has run -- 19.2 of the 37 MB of a C2 step, hidden behind the
+    deformation backward.  `early=[param]` puts those slots first; `early_reduce(param, grad)` (called from a
+    tensor hook) copies and launches; all_reduce() then only handles the remaining slots.  The layout is
+    learnt on the first step (which parameters are live is only known after a backward), so the first step
+    -- and any step after the set of live parameters changed -- reduces everything at the end."""
 
     ALIGN = 64
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params: Iterable[torch.nn.Parameter], early: Iterable[torch.nn.Parameter] = ()):
+        early = list(early)
+        early_ids = {id(p) for p in early}
+        rest = [p for p in params if p.requires_grad and id(p) not in early_ids]
+        self.params = [p for p in early if p.requires_grad] + rest      # early slots first
+        self.early_ids = early_ids
         self.flat = None
         self.live = None
         self.slots = None
-        self._pending = None
+        self.split = 0                 # floats of the early region
+        self._pending = []
+        self._early_done = set()
 
-    def _ensure(self):
-        live = [p for p in self.params if p.grad is not None]
-        if self.flat is None or [id(p) for p in live] != [id(p) for p in (self.live or [])]:
-            self.live = live
-            offs, total = [], 0
-            for p in live:
-                offs.append(total)
-                total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-            dev = live[0].device if live else "cpu"
-            self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
-            self.slots = [self.flat[o:o + p.numel()] for o, p in zip(offs, live)]
-        return self.live
+    def _layout(self, live):
+        offs, total, split = [], 0, 0
+        for p in live:
+            offs.append(total)
+            total += (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if id(p) in self.early_ids:
+                split = total
+        dev = live[0].device if live else "cpu"
+        self.live = live
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.slots = [self.flat[o:o + p.numel()] for o, p in zip(offs, live)]
+        self.split = split
+
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def early_reduce(self, param, grad, force: bool = False) -> bool:
+        """Start the all-reduce of `param`'s gradient now (grad: the final gradient, any dense layout matching
+        the parameter).  Returns False -- and does nothing -- while the layout is not known yet.
+        force=True runs the bookkeeping and the copy without a process group (single-process tests)."""
+        if self.flat is None or not (force or self._active()) or id(param) not in self.early_ids:
+            return False
+        for p, slot in zip(self.live, self.slots):
+            if p is param:
+                slot.copy_(_memory_order_view(grad))
+                if self._active():
+                    self._pending.append(dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True))
+                self._early_done.add(id(param))
+                return True
+        return False
 
     def all_reduce(self, async_op: bool = False):
-        """Sum gradients over all ranks in place.  Returns the work handle when async_op."""
-        live = self._ensure()
-        if not live or not dist.is_initialized() or dist.get_world_size() == 1:
+        """Sum gradients over all ranks in place.  Returns the work handles when async_op."""
+        live = [p for p in self.params if p.grad is not None]
+        if self.flat is None or [id(p) for p in live] != [id(p) for p in (self.live or [])]:
+            if self._early_done:
+                # the layout changed under an early reduce: wait for it, then redo everything at the end
+                for w in self._pending:
+                    w.wait()
+                self._pending, self._early_done = [], set()
+            self._layout(live)
+        if not live or not self._active():
+            self._early_done = set()
             return None
+        todo = [(slot, p) for slot, p in zip(self.slots, live) if id(p) not in self._early_done]
         # .reshape(-1) would copy channels-last plane grads into logical order; keep memory order instead
-        torch._foreach_copy_(self.slots, [_memory_order_view(p.grad) for p in live])
-        self._pending = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+        torch._foreach_copy_([s for s, _ in todo], [_memory_order_view(p.grad) for _, p in todo])
+        all_early_done = all(id(p) in self._early_done for p in live if id(p) in self.early_ids)
+        region = self.flat[self.split:] if (all_early_done and self.split) else self.flat
+        if region.numel():
+            self._pending.append(dist.all_reduce(region, op=dist.ReduceOp.SUM, async_op=True))
         if not async_op:
             self.finish()
             return None
         return self._pending
 
     def finish(self):
-        work = self._pending
-        if work is None:
+        if not self._pending:
+            self._early_done = set()
             return
-        work.wait()
-        self._pending = None
+        for w in self._pending:
+            w.wait()
+        self._pending, self._early_done = [], set()
         for p, slot in zip(self.live, self.slots):
             p.grad = _like_memory_order(slot, p.grad)
 

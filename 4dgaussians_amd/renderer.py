@@ -44,9 +44,11 @@ class Camera:
 
 
 def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
-           scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False):
+           scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False, shs_grad_hook=None):
     """-> (image, screenspace_points, visibility_filter, radii, depth), as the first five items of the
-    reference's 7-tuple (renderer.py:221)."""
+    reference's 7-tuple (renderer.py:221).  shs_grad_hook(grad), if given, is called during the backward pass as soon
+    as dL/d(deformed SH coefficients) exists, i.e. before the deformation backward runs (data-parallel training
+    starts the all-reduce of the SH gradients there, parallel.GradBucket.early_reduce)."""
     screenspace_points = torch.zeros_like(pc._xyz, requires_grad=torch.is_grad_enabled())
     if screenspace_points.requires_grad:
         screenspace_points.retain_grad()
@@ -65,6 +67,8 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
         force = torch.full((n, 1), cam.force, dtype=torch.float32, device=means3D.device)
         means3D, scales, rotations, opacity, shs = deform.forward_dynamic(means3D, scales, rotations, opacity, shs,
                                                                           time, force, None)
+        if shs_grad_hook is not None and shs.requires_grad:
+            shs.register_hook(shs_grad_hook)
     scales, rotations, opacity = activate(scales, rotations, opacity)    # exp / L2-normalise / sigmoid, one kernel
     image, radii, depth = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
                                      opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)

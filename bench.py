@@ -154,10 +154,16 @@ def main():
     raw = dict(raw, log_scales=(raw["log_scales"] + np.float32(log_s0_offset)).astype(np.float32))
     all_params = list(pc.parameters()) + list(deform.parameters())
     # ONE flat bucket for the Gaussian and the deformation gradients: one pack, one all-reduce per step
-    bucket = par.GradBucket(all_params)
+    # (the SH gradients are final before the deformation backward runs: their all-reduce starts from a tensor hook)
+    bucket = par.GradBucket(all_params, early=[pc._features])
+
+    def shs_hook(g):
+        bucket.early_reduce(pc._features, g)
+
+    hook = shs_hook if world > 1 else None
 
     def train_step():
-        image, *_ = R.render(cam, pc, deform, bg)
+        image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
         loss = F.l1_loss(image, target)
         if world > 1:
             loss = loss / world                           # SUM over ranks == mean over the global batch
@@ -305,7 +311,7 @@ def main():
             {"params": [pc._rotation], "lr": 0.001, "name": "rotation"}], lr=0.0001, eps=1e-8)
 
         def opt_step():
-            image, *_ = R.render(cam, pc, deform, bg)
+            image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
             loss = F.l1_loss(image, target) + reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
             if world > 1:
                 loss = loss / world

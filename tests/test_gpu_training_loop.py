@@ -75,3 +75,36 @@ def test_train_densify_save_load_render(tmp_path):
         np.testing.assert_array_equal(a, b)
     img = RD.render_for_image(cams[0], h, h._deformation, bg)
     assert float(IU.psnr(img[None], targets[0][None])) > 5.0
+
+
+def test_early_sh_gradient_equals_final_feature_gradient():
+    """parallel.GradBucket.early_reduce relies on dL/d_features == dL/d(deformed shs) (the deformation adds a residual
+    to the SH coefficients): the gradient seen by render()'s shs_grad_hook, mid-backward, must be bit-identical to
+    the gradient autograd finally delivers to the parameter, and the bucket must hand it back unchanged."""
+    RD, F, syn, par = pkg("renderer"), pkg("fused"), pkg("synthetic"), pkg("parallel")
+    cfg = R.DeformConfig(plane_channels=16, resolution=[16, 16, 16, 8], multires=[1, 2])
+    torch.manual_seed(1)
+    dev = torch.device("cuda")
+    deform = pkg("scene.deformation").deform_network(make_args(cfg)).to(dev)
+    _, cam_np, raw = syn.make_workload("C1", P=3000)
+    pc = RD.GaussianParams(raw, dev)
+    cam = RD.Camera(syn.look_at_camera(128, 96), dev, time=0.4)
+    params = list(pc.parameters()) + list(deform.parameters())
+    bucket = par.GradBucket(params, early=[pc._features])
+    target = torch.rand(3, 96, 128, device=dev)
+    seen = []
+    for step in range(2):
+        def hook(g):
+            seen.append((bucket.early_reduce(pc._features, g, force=True), g.detach().clone()))
+        image, *_ = RD.render(cam, pc, deform, torch.ones(3, device=dev), shs_grad_hook=hook)
+        F.l1_loss(image, target).backward()
+        assert len(seen) == step + 1
+        started, g_mid = seen[-1]
+        assert started == (step > 0)                       # the layout is learnt by the first all_reduce()
+        assert torch.equal(g_mid, pc._features.grad)
+        if started:
+            slot = [s for p, s in zip(bucket.live, bucket.slots) if p is pc._features][0]
+            assert torch.equal(slot.view_as(g_mid), g_mid) and bucket.split >= g_mid.numel()
+        bucket.all_reduce()                                # single process: builds the layout, reduces nothing
+        for p in params:
+            p.grad = None

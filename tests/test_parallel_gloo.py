@@ -37,6 +37,22 @@ def _worker(rank, world, port, out):
     assert plane.grad.is_contiguous(memory_format=torch.channels_last)
     assert b.nbytes == (15 + 24) * 4
     assert par.views_for_rank(8, rank, world) == list(range(rank, 8, 2))
+    # early parameters: step 1 learns the layout (everything reduced at the end), step 2 starts `e` early
+    e = torch.nn.Parameter(torch.zeros(9))
+    late = torch.nn.Parameter(torch.zeros(70))
+    be = par.GradBucket([late, e, dead], early=[e])
+    for step in range(3):
+        ge = torch.full((9,), float(10 * step + rank + 1))
+        started = be.early_reduce(e, ge)                 # what a tensor hook would do mid-backward
+        assert started == (step > 0)
+        e.grad = ge.clone()                              # autograd delivers the same values at the end
+        late.grad = torch.arange(70, dtype=torch.float32) * (rank + 1) + step
+        be.all_reduce()
+        assert torch.equal(e.grad, torch.full((9,), float(20 * step + 3)))
+        assert torch.equal(late.grad, torch.arange(70, dtype=torch.float32) * 3 + 2 * step)
+        assert e.grad.data_ptr() % 16 == 0 and late.grad.data_ptr() % 16 == 0
+        e.grad = late.grad = None
+    assert be.split == 64 and be.nbytes == (9 + 70) * 4
     if rank == 0:
         open(out, "w").write("ok")
     dist.barrier()
