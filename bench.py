@@ -68,6 +68,14 @@ def deform_args(name: str):
     return a
 
 
+_T0 = time.perf_counter()
+
+
+def _dbg(msg):
+    if os.environ.get("GS4D_BENCH_DEBUG"):
+        print(f"[bench rank {os.environ.get('RANK', '0')} +{time.perf_counter() - _T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -81,15 +89,22 @@ def main():
     ap.add_argument("--no-stage-events", action="store_true",
                     help="do not record per-stage HIP events in the timed region (then no roofline / stages_ms)")
     args = ap.parse_args()
+    if os.environ.get("GS4D_BENCH_DEBUG", "").isdigit() and int(os.environ["GS4D_BENCH_DEBUG"]) > 1:
+        import faulthandler                       # GS4D_BENCH_DEBUG=<seconds>: dump every thread's stack if still running then
+        faulthandler.dump_traceback_later(int(os.environ["GS4D_BENCH_DEBUG"]), exit=False)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
+        # RCCL ("nccl") on a multi-GPU node; GS4D_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
+        # multi-rank code path on a single-GPU box (collectives then go through host memory)
+        dist.init_process_group(os.environ.get("GS4D_DIST_BACKEND", "nccl"))
+    _dbg("process group ready")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU product path)")
+    local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -113,6 +128,7 @@ def main():
     if world > 1:  # replicas start identical
         for p in list(pc.parameters()) + list(deform.parameters()):
             dist.broadcast(par._memory_order_view(p.data), 0)      # a contiguous 1-D view, also of channels-last planes
+    _dbg("parameters replicated")
     # each rank looks at the scene from its own azimuth / timestamp (view-parallel)
     rng = np.random.default_rng(1234 + rank)
     cam_np = syn.look_at_camera(W, H, azimuth=0.7 + 0.6 * rank)
@@ -151,6 +167,7 @@ def main():
         with torch.no_grad():
             pc._scaling.add_(float(off.item()) - log_s0_offset)
         log_s0_offset = float(off.item())
+    _dbg(f"scene calibrated, offset {log_s0_offset:.4f}")
     raw = dict(raw, log_scales=(raw["log_scales"] + np.float32(log_s0_offset)).astype(np.float32))
     all_params = list(pc.parameters()) + list(deform.parameters())
     # ONE flat bucket for the Gaussian and the deformation gradients: one pack, one all-reduce per step
@@ -192,17 +209,21 @@ def main():
     # passes over the young generations cheap (a full collection in the timed region cost ~36 ms once)
     gc.collect()
     gc.freeze()
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         step()
+        _dbg(f"warmup step {i} issued")
     sync()
+    _dbg("warmup done")
     L.gs4d_profile_reset()
     L.gs4d_profile_select(None if args.no_stage_events else dominant.encode())
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        _dbg(f"timed step {i} issued")
     sync()
     dt = time.perf_counter() - t0
+    _dbg(f"timed region done: {dt / args.steps * 1e3:.3f} ms per step")
     L.gs4d_profile_enable(0)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
