@@ -16,6 +16,39 @@ def views_for_rank(batch: int, rank: int, world: int) -> List[int]:
     return list(range(rank, batch, world))
 
 
+def all_reduce_densification_stats(viewspace_grad: torch.Tensor, radii: torch.Tensor, visibility: torch.Tensor):
+    """The three small exchanges a densifying iteration adds (collectives 2-4), so that every rank
+    accumulates the SAME statistics and densify / prune then change P identically everywhere:
+      * SUM of the raw screen-space gradients (P,3): the reference adds them over the batch BEFORE taking the
+        norm (train.py:229-233 -> scene/gaussian_model.py:613-615),
+      * MAX of the int32 radii (P,) (train.py:199, max_radii2D update at train.py:302),
+      * OR of the visibility filters (P,) (train.py:200).
+    radii and visibility travel as one int32 [2,P] MAX all-reduce.  Returns (grad_sum, radii_max, visible_any);
+    without a process group the inputs come back unchanged."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return viewspace_grad, radii, visibility
+    g = viewspace_grad.detach().clone().contiguous()
+    work = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+    iv = torch.stack([radii.to(torch.int32), visibility.to(torch.int32)]).contiguous()
+    dist.all_reduce(iv, op=dist.ReduceOp.MAX)
+    work.wait()
+    return g, iv[0].to(radii.dtype), iv[1].to(torch.bool)
+
+
+def seed_all_ranks(tag: int = 0, device=None) -> int:
+    """Rank 0 draws a seed, every rank adopts it: densify_and_split samples new positions with torch.normal
+    (scene/gaussian_model.py:446), and replicas must draw the same samples to stay identical.  Call it right
+    before densify() on a densifying iteration.  Returns the seed."""
+    seed = torch.randint(0, 2 ** 31 - 1, (1,), dtype=torch.int64) + int(tag)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dev = device if device is not None else ("cuda" if dist.get_backend() == "nccl" else "cpu")
+        t = seed.to(dev)
+        dist.broadcast(t, 0)
+        seed = t.cpu()
+    torch.manual_seed(int(seed.item()))        # seeds the CPU and every GPU generator of this process
+    return int(seed.item())
+
+
 class GradBucket:
     """Flat fp32 bucket over the parameters that actually receive gradients (the reference's dead
     parameters -- prev_frame_encoder.*, feature_out1, force_embedder, grid.feature_aggr.*,

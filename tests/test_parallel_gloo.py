@@ -59,6 +59,63 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _densify_worker(rank, world, port, out):
+    """Two replicas see different views (different screen-space gradients, radii, visibility); after the three
+    statistic exchanges and a shared seed, densify + prune leave both with the SAME Gaussians."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    from test_gaussian_model_host import model
+    m = model(80, seed=3)                                   # identical replicas
+    g = torch.Generator().manual_seed(100 + rank)           # rank-specific "views"
+    vs_grad = torch.randn(80, 3, generator=g) * 1e-3
+    radii = torch.randint(0, 60, (80,), generator=g, dtype=torch.int32)
+    vis = radii > 20
+    gs, rmax, vany = par.all_reduce_densification_stats(vs_grad, radii, vis)
+    both_g = [torch.zeros_like(vs_grad) for _ in range(world)]
+    both_r = [torch.zeros_like(radii) for _ in range(world)]
+    dist.all_gather(both_g, vs_grad)
+    dist.all_gather(both_r, radii)
+    assert torch.equal(gs, both_g[0] + both_g[1])
+    assert torch.equal(rmax, torch.maximum(both_r[0], both_r[1])) and rmax.dtype == torch.int32
+    assert torch.equal(vany, (both_r[0] > 20) | (both_r[1] > 20)) and vany.dtype == torch.bool
+    m.max_radii2D[vany] = torch.max(m.max_radii2D[vany], rmax[vany].float())        # train.py:302
+    m.add_densification_stats(gs, vany)
+    torch.manual_seed(rank)                                 # the replicas' generators have drifted apart ...
+    seed = par.seed_all_ranks(tag=7)                        # ... and are brought together before the split samples
+    m.percent_dense = 0.05
+    m.densify(0.0012, 0.005, 1.0, 40)
+    m.prune(0.0012, 0.005, 1.0, 40)
+    n = torch.tensor([m.get_xyz.shape[0], seed])
+    ns = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(ns, n)
+    assert torch.equal(ns[0], ns[1]) and int(ns[0][0]) != 80
+    for name in ("_xyz", "_scaling", "_rotation", "_opacity", "_features_dc"):
+        mine = getattr(m, name).detach().contiguous()
+        parts = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        assert torch.equal(parts[0], parts[1]), name
+    if rank == 0:
+        open(out, "w").write("ok %d" % int(ns[0][0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_densification_stays_rank_consistent_world2(tmp_path):
+    out = str(tmp_path / "done")
+    mp.spawn(_densify_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert open(out).read().startswith("ok")
+
+
+def test_densification_stats_without_process_group():
+    par = importlib.import_module("4dgaussians_amd.parallel")
+    g, r, v = torch.ones(4, 3), torch.arange(4, dtype=torch.int32), torch.tensor([True, False, True, False])
+    g2, r2, v2 = par.all_reduce_densification_stats(g, r, v)
+    assert g2 is g and r2 is r and v2 is v
+
+
 def test_grad_bucket_allreduce_world2(tmp_path):
     out = str(tmp_path / "done")
     mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
