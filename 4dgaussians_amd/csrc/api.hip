@@ -154,7 +154,7 @@ static int sort_passes(int W, int H)
 extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
-int gs4d_abi_version(void) { return 4; }
+int gs4d_abi_version(void) { return 5; }
 
 void gs4d_profile_enable(int on)
 {

@@ -1509,16 +1509,21 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
     return GS4D_OK;
 }
 
-int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P, const float* points,
-                         const float* scales, const float* rotations, const float* time, const float* force,
-                         const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations,
-                         const float* dL_dshs, float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in,
-                         float* dL_dshs_in, char* workspace, char* scratch, void* stream)
+int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P, const float* points,
+                                const float* scales, const float* rotations, const float* time, const float* force,
+                                const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations,
+                                const float* dL_dshs, float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in,
+                                float* dL_dshs_in, char* workspace, char* scratch, void* stream, int phases)
 {
     hipStream_t s = (hipStream_t)stream;
     int rc = validate(d, P);
     if (rc) return rc;
     if (P == 0) return GS4D_OK;
+    if (phases < 1 || phases > (GS4D_DEFORM_BWD_DATA | GS4D_DEFORM_BWD_WEIGHTS)) {
+        gs4d_set_error("gs4d_deform_backward_phases: phases must be a combination of GS4D_DEFORM_BWD_DATA and _WEIGHTS");
+        return GS4D_EINVAL;
+    }
+    const bool do_data = (phases & GS4D_DEFORM_BWD_DATA) != 0, do_weights = (phases & GS4D_DEFORM_BWD_WEIGHTS) != 0;
     if (!g || !points || !scales || !rotations || !time || !force || !dL_dmeans3D || !dL_dscales || !dL_drotations ||
         !dL_dshs || !dL_dpoints || !dL_dscales_in || !dL_drotations_in || !dL_dshs_in || !workspace || !scratch ||
         ((uintptr_t)workspace & 255) || ((uintptr_t)scratch & 255) || ((uintptr_t)rotations & 15) ||
@@ -1537,16 +1542,20 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
                   &key, &rec, &slabs, &slab_per_job, nullptr);
     const int nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
 
-    Gs4dProfScope* mlp_scope = new Gs4dProfScope("mlp_backward", s);
+    // Order: everything the INPUT and PLANE gradients need first (data phase), the weight-gradient products
+    // last (weights phase), so that a data-parallel caller can start exchanging the former while the latter run.
+    Gs4dProfScope* mlp_scope = do_data ? new Gs4dProfScope("mlp_backward", s) : nullptr;
     struct ScopeGuard { Gs4dProfScope*& p; ~ScopeGuard() { delete p; } } mlp_guard{mlp_scope};
     OutArgs oa = {P, d->no_dx, d->no_ds, d->no_dr, d->no_dshs, d->apply_rotation};
-    hipLaunchKernelGGL(outputs_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, oa, w.O, rotations,
-                       dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dO, dL_dpoints, dL_dscales_in,
-                       dL_drotations_in, dL_dshs_in);
-    GS4D_LAUNCH_CHECK("deform_outputs_backward", 0, s);
+    if (do_data) {
+        hipLaunchKernelGGL(outputs_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, oa, w.O, rotations,
+                           dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dO, dL_dpoints, dL_dscales_in,
+                           dL_drotations_in, dL_dshs_in);
+        GS4D_LAUNCH_CHECK("deform_outputs_backward", 0, s);
+    }
 
     // dH1_h = (dO_h W2_h) * (H1_h > 0)
-    {
+    if (do_data) {
         GemmJobs jobs = {};
         for (int h = 0; h < NHEAD; h++) {
             GemmJob& j = jobs.j[h];
@@ -1558,7 +1567,7 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         if (rc) return rc;
     }
     // dZ = (sum_h dH1_h W1_h scattered to Z columns) * (Z > 0): the hidden columns and the three PE segments
-    {
+    if (do_data) {
         GemmJobs jobs = {};
         int nj = 0;
         auto all_heads = [&](int zcol0, int ncols, int wcol_of_head[NHEAD]) {
@@ -1608,8 +1617,10 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
             jj = j;
             jj.b_col0[0] = c0; jj.ycol0 = c0; jj.N = K - c0 > 64 ? 64 : K - c0;
         }
-        rc = launch_gemm(P, jobs, nj, s);
-        if (rc) return rc;
+        if (do_data) {
+            rc = launch_gemm(P, jobs, nj, s);
+            if (rc) return rc;
+        }
         DwJob q = {};
         q.G = dcur; q.ldg = dcur_ld; q.gcol0 = 0; q.N = WIDTH;
         q.X = i == 0 ? w.feat : w.trunk[i - 1]; q.ldx = K; q.x_nseg = 1; q.x_beg[0] = 0; q.x_len[0] = K; q.K = K;
@@ -1640,17 +1651,10 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         b.slabs = slabs + slab_per_job * (NHEAD + h); b.dW = g->head_w2[h]; b.db = g->head_b2[h];
         add_dw(b);
     }
-    {
-        dj.njobs = ndw; dj.nz = (kbmax + 5) / 6; dj.nchunks = nchunks;
-        const int grid = (nchunks + 7) / 8 * 8 * ndw * dj.nz;
-        hipLaunchKernelGGL(dw_partial_kernel, dim3(grid), dim3(256), 0, s, P, dj);
-        hipLaunchKernelGGL(dw_reduce_kernel, dim3((nkmax + 63) / 64, ndw), dim3(256), 0, s, nchunks, dj);
-        GS4D_LAUNCH_CHECK("deform_dw", 0, s);
-    }
     // PE tails -> inputs (accumulates onto the pass-through gradients written by outputs_backward)
     PeArgs pa = {P, l.ldz, l.oX, l.oS, l.oR, l.oT, l.oF, l.Kz, d->pos_pe, d->sr_pe, d->time_pe, d->force_pe,
                  d->use_time, d->use_force};
-    {
+    if (do_data) {
         const size_t threads = (size_t)P * 10;
         hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pa, points,
                            scales, rotations, dZ, dL_dpoints, dL_dscales_in, dL_drotations_in);
@@ -1659,7 +1663,7 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
     delete mlp_scope;
     mlp_scope = nullptr;
     // planes, xyz through the planes, t'
-    {
+    if (do_data) {
         GS4D_PROF("hexplane_backward", s);
         PlaneTable T = {};
         for (int i = 0; i < d->L * 6; i++) {
@@ -1702,7 +1706,27 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
         hipLaunchKernelGGL(ft_embed_final_kernel, dim3(1), dim3(256), 0, s, nred, dtprime, g->ft_w, g->ft_b);
         GS4D_LAUNCH_CHECK("deform_tail_backward", 0, s);
     }
+    // every weight-gradient product of the network (reads dO, dH1, dZ, dT and the forward activations)
+    if (do_weights) {
+        GS4D_PROF("weight_grads", s);
+        dj.njobs = ndw; dj.nz = (kbmax + 5) / 6; dj.nchunks = nchunks;
+        const int grid = (nchunks + 7) / 8 * 8 * ndw * dj.nz;
+        hipLaunchKernelGGL(dw_partial_kernel, dim3(grid), dim3(256), 0, s, P, dj);
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3((nkmax + 63) / 64, ndw), dim3(256), 0, s, nchunks, dj);
+        GS4D_LAUNCH_CHECK("deform_dw", 0, s);
+    }
     return GS4D_OK;
+}
+
+int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P, const float* points,
+                         const float* scales, const float* rotations, const float* time, const float* force,
+                         const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations,
+                         const float* dL_dshs, float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in,
+                         float* dL_dshs_in, char* workspace, char* scratch, void* stream)
+{
+    return gs4d_deform_backward_phases(d, g, P, points, scales, rotations, time, force, dL_dmeans3D, dL_dscales,
+                                       dL_drotations, dL_dshs, dL_dpoints, dL_dscales_in, dL_drotations_in, dL_dshs_in,
+                                       workspace, scratch, stream, GS4D_DEFORM_BWD_DATA | GS4D_DEFORM_BWD_WEIGHTS);
 }
 
 }  // extern "C"

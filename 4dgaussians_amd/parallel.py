@@ -80,6 +80,7 @@ class GradBucket:
         self.live = None
         self.slots = None
         self.split = 0                 # floats of the early region
+        self._live_ids = None
         self._pending = []
         self._early_done = set()
 
@@ -95,9 +96,21 @@ class GradBucket:
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
         self.slots = [self.flat[o:o + p.numel()] for o, p in zip(offs, live)]
         self.split = split
+        # per-step work is kept to list lookups: slot index of every live parameter, slot bounds, and the views of
+        # the bucket that finish() installs as .grad (same shape and memory format as the gradient autograd produced)
+        self._index = {id(p): i for i, p in enumerate(live)}
+        self._bounds = [(o, o + p.numel()) for o, p in zip(offs, live)]
+        self._live_ids = [id(p) for p in live]
+        self._grad_views = [_like_memory_order(slot, p.grad) for slot, p in zip(self.slots, live)]
+
+    # exchange even in a world of one rank: lets a one-GPU box run the real collectives (RCCL work handles, stream
+    # ordering, hooks on the autograd thread) of the multi-rank path; see tests/test_gpu_dp_single_rank.py
+    exchange_in_world_of_one = False
 
     def _active(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or self.exchange_in_world_of_one
 
     def early_reduce(self, param, grad, force: bool = False) -> bool:
         """Start the all-reduce of `param`'s gradient now (grad: the final gradient, any dense layout matching
@@ -105,19 +118,40 @@ class GradBucket:
         force=True runs the bookkeeping and the copy without a process group (single-process tests)."""
         if self.flat is None or not (force or self._active()) or id(param) not in self.early_ids:
             return False
-        for p, slot in zip(self.live, self.slots):
-            if p is param:
-                slot.copy_(_memory_order_view(grad))
-                if self._active():
-                    self._pending.append(dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True))
-                self._early_done.add(id(param))
-                return True
-        return False
+        i = self._index.get(id(param))
+        if i is None:
+            return False
+        slot = self.slots[i]
+        slot.copy_(_memory_order_view(grad))
+        if self._active():
+            self._pending.append(dist.all_reduce(slot, op=dist.ReduceOp.SUM, async_op=True))
+        self._early_done.add(id(param))
+        return True
+
+    def early_reduce_many(self, params, grads, force: bool = False) -> bool:
+        """early_reduce for several parameters at once: one multi-tensor copy and ONE all-reduce over the bucket
+        range that spans their slots.  The parameters must occupy consecutive slots (list them consecutively in
+        `early=`) so that the range holds nothing else; returns False -- and does nothing -- otherwise, or while
+        the layout is not known yet, or if one of them is not live."""
+        if self.flat is None or not (force or self._active()) or not params:
+            return False
+        ids = [self._index.get(id(p)) for p in params]
+        if any(i is None or id(p) not in self.early_ids for i, p in zip(ids, params)):
+            return False
+        lo, hi = min(ids), max(ids)
+        if hi - lo + 1 != len(ids) or len(set(ids)) != len(ids):
+            return False
+        torch._foreach_copy_([self.slots[i] for i in ids], [_memory_order_view(g) for g in grads])
+        if self._active():
+            self._pending.append(dist.all_reduce(self.flat[self._bounds[lo][0]:self._bounds[hi][1]],
+                                                 op=dist.ReduceOp.SUM, async_op=True))
+        self._early_done.update(id(p) for p in params)
+        return True
 
     def all_reduce(self, async_op: bool = False):
         """Sum gradients over all ranks in place.  Returns the work handles when async_op."""
         live = [p for p in self.params if p.grad is not None]
-        if self.flat is None or [id(p) for p in live] != [id(p) for p in (self.live or [])]:
+        if self.flat is None or [id(p) for p in live] != self._live_ids:
             if self._early_done:
                 # the layout changed under an early reduce: wait for it, then redo everything at the end
                 for w in self._pending:
@@ -129,11 +163,21 @@ class GradBucket:
             return None
         todo = [(slot, p) for slot, p in zip(self.slots, live) if id(p) not in self._early_done]
         # .reshape(-1) would copy channels-last plane grads into logical order; keep memory order instead
-        torch._foreach_copy_([s for s, _ in todo], [_memory_order_view(p.grad) for _, p in todo])
-        all_early_done = all(id(p) in self._early_done for p in live if id(p) in self.early_ids)
-        region = self.flat[self.split:] if (all_early_done and self.split) else self.flat
-        if region.numel():
-            self._pending.append(dist.all_reduce(region, op=dist.ReduceOp.SUM, async_op=True))
+        if todo:
+            torch._foreach_copy_([s for s, _ in todo], [_memory_order_view(p.grad) for _, p in todo])
+        # one all-reduce per run of consecutive slots that were not reduced early: the whole bucket when nothing
+        # was, flat[split:] when every early parameter was (the two usual cases), several ranges otherwise
+        total, run_begin = self.flat.numel(), None
+        for i, p in enumerate(live):
+            begin = self._bounds[i][0]
+            if id(p) in self._early_done:
+                if run_begin is not None:
+                    self._pending.append(dist.all_reduce(self.flat[run_begin:begin], op=dist.ReduceOp.SUM, async_op=True))
+                    run_begin = None
+            elif run_begin is None:
+                run_begin = begin
+        if run_begin is not None:
+            self._pending.append(dist.all_reduce(self.flat[run_begin:total], op=dist.ReduceOp.SUM, async_op=True))
         if not async_op:
             self.finish()
             return None
@@ -146,8 +190,8 @@ class GradBucket:
         for w in self._pending:
             w.wait()
         self._pending, self._early_done = [], set()
-        for p, slot in zip(self.live, self.slots):
-            p.grad = _like_memory_order(slot, p.grad)
+        for p, view in zip(self.live, self._grad_views):
+            p.grad = view
 
     @property
     def nbytes(self) -> int:

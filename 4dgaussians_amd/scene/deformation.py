@@ -22,6 +22,7 @@ from .. import _cabi
 from .hexplane import HexPlaneField
 
 MAX_LEVELS, MAX_TRUNK = 4, 8
+BWD_DATA, BWD_WEIGHTS = 1, 2          # GS4D_DEFORM_BWD_* of include/gs4d.h
 FP = C.c_void_p
 
 
@@ -154,13 +155,25 @@ class _DeformFunction(torch.autograd.Function):
         d_xyz, d_sc, d_rot, d_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, g_shs))
         scratch = torch.empty(max(int(L.gs4d_deform_backward_scratch_bytes(C.byref(d), C.c_int(P))), 256),
                               dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
-            rc = L.gs4d_deform_backward(C.byref(d), C.byref(g), C.c_int(P), _cabi.ptr(points_), _cabi.ptr(scales_),
-                                        _cabi.ptr(rot_), _cabi.ptr(time_), _cabi.ptr(force_), _cabi.ptr(g_xyz),
-                                        _cabi.ptr(g_sc), _cabi.ptr(g_rot), _cabi.ptr(g_shs), _cabi.ptr(d_xyz),
-                                        _cabi.ptr(d_sc), _cabi.ptr(d_rot), _cabi.ptr(d_shs), _cabi.ptr(ws),
-                                        _cabi.ptr(scratch), _cabi.current_stream(dev))
-        _cabi.check(rc, "gs4d_deform_backward")
+        hook = cfg.get("data_grad_hook")
+
+        def run(phases):
+            with torch.cuda.device(dev):
+                rc = L.gs4d_deform_backward_phases(
+                    C.byref(d), C.byref(g), C.c_int(P), _cabi.ptr(points_), _cabi.ptr(scales_), _cabi.ptr(rot_),
+                    _cabi.ptr(time_), _cabi.ptr(force_), _cabi.ptr(g_xyz), _cabi.ptr(g_sc), _cabi.ptr(g_rot),
+                    _cabi.ptr(g_shs), _cabi.ptr(d_xyz), _cabi.ptr(d_sc), _cabi.ptr(d_rot), _cabi.ptr(d_shs), _cabi.ptr(ws),
+                    _cabi.ptr(scratch), _cabi.current_stream(dev), C.c_int(phases))
+            _cabi.check(rc, "gs4d_deform_backward_phases")
+
+        if hook is None:
+            run(BWD_DATA | BWD_WEIGHTS)
+        else:
+            # data-parallel overlap: everything but the Linear weight gradients is final after the data phase and can
+            # start its all-reduce while the weight-gradient products run (parallel.GradBucket.early_reduce_many)
+            run(BWD_DATA)
+            hook(d_xyz, d_sc, d_rot, gp, g_ftw, g_ftb)
+            run(BWD_WEIGHTS)
         param_grads = gp + [None, g_ftw, g_ftb] + gt + gh
         return (d_xyz, d_sc, d_rot, d_shs, None, None, None, *param_grads)
 
@@ -180,6 +193,9 @@ class Deformation(nn.Module):
         self.extra_opacity_dim = args.opacity_pe * 2 * 3
         self.prev_frames = args.prev_frames
         self.prev_frames_out_dim = 16
+        # optional callable(d_points, d_scales, d_rotations, plane_grads, ft_w_grad, ft_b_grad), called from the
+        # backward as soon as those gradients are final (before the weight gradients are computed); see parallel.py
+        self.data_grad_hook = None
         self.create_net()
 
     @property
@@ -236,7 +252,8 @@ class Deformation(nn.Module):
                     pos_pe=int(self.posbase_pe), sr_pe=int(self.scale_rotation_pe), time_pe=int(self.time_pe),
                     force_pe=int(self.force_pe), no_dx=int(bool(a.no_dx)), no_ds=int(bool(a.no_ds)),
                     no_dr=int(bool(a.no_dr)), no_dshs=int(bool(a.no_dshs)), apply_rotation=int(bool(a.apply_rotation)),
-                    use_time=int(bool(a.use_time)), use_force=int(bool(a.use_force)))
+                    use_time=int(bool(a.use_time)), use_force=int(bool(a.use_force)),
+                    data_grad_hook=self.data_grad_hook)
 
     def _params(self):
         planes = [p for level in self.grid.grids for p in level]

@@ -48,7 +48,7 @@ FP32_PEAK_TFLOPS = 157.3   # vector / f32-MFMA peak
 
 STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges",
           "blend_forward", "l1_loss_forward", "l1_loss_backward", "blend_backward", "geom_backward",
-          "activate_backward", "mlp_backward", "hexplane_backward", "plane_reg_forward", "plane_reg_backward", "adamw")
+          "activate_backward", "mlp_backward", "hexplane_backward", "weight_grads", "plane_reg_forward", "plane_reg_backward", "adamw")
 
 
 def deform_args(name: str):
@@ -77,6 +77,11 @@ def _dbg(msg):
 
 
 def main():
+    # stdout carries the ONE JSON line and nothing else: whatever a library prints there (RCCL's version banner at
+    # communicator set-up) is sent to stderr
+    result_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -96,11 +101,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # GS4D_BENCH_REHEARSE_DP=1 with one rank: run the multi-rank code path (hooks, bucket, RCCL all-reduces) in a
+    # process group of ONE rank -- the rehearsal a one-GPU box allows; the line then says "rehearsal" and is no result
+    rehearse = world == 1 and bool(os.environ.get("GS4D_BENCH_REHEARSE_DP"))
+    dp = world > 1 or rehearse
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") on a multi-GPU node; GS4D_DIST_BACKEND=gloo lets several ranks share one GPU to rehearse the
-        # multi-rank code path on a single-GPU box (collectives then go through host memory)
-        dist.init_process_group(os.environ.get("GS4D_DIST_BACKEND", "nccl"))
+        os.environ.setdefault("MASTER_PORT", "29577")
+        # RCCL ("nccl") on a multi-GPU node; GS4D_DIST_BACKEND=gloo routes the collectives through host memory
+        dist.init_process_group(os.environ.get("GS4D_DIST_BACKEND", "nccl"), rank=rank, world_size=world)
     _dbg("process group ready")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU product path)")
@@ -125,7 +134,8 @@ def main():
     deform = Dm.deform_network(deform_args(args.config))
     deform.deformation_net.set_aabb([1.3, 1.3, 1.3], [-1.3, -1.3, -1.3])
     deform = deform.to(dev)
-    if world > 1:  # replicas start identical
+    if dp:  # replicas start identical
+        par.GradBucket.exchange_in_world_of_one = rehearse
         for p in list(pc.parameters()) + list(deform.parameters()):
             dist.broadcast(par._memory_order_view(p.data), 0)      # a contiguous 1-D view, also of channels-last planes
     _dbg("parameters replicated")
@@ -161,7 +171,7 @@ def main():
         log_s0_offset += d
         with torch.no_grad():
             pc._scaling.add_(d)
-    if world > 1:
+    if dp:
         off = torch.tensor([log_s0_offset], dtype=torch.float64, device=dev)
         dist.broadcast(off, 0)
         with torch.no_grad():
@@ -170,23 +180,45 @@ def main():
     _dbg(f"scene calibrated, offset {log_s0_offset:.4f}")
     raw = dict(raw, log_scales=(raw["log_scales"] + np.float32(log_s0_offset)).astype(np.float32))
     all_params = list(pc.parameters()) + list(deform.parameters())
-    # ONE flat bucket for the Gaussian and the deformation gradients: one pack, one all-reduce per step
-    # (the SH gradients are final before the deformation backward runs: their all-reduce starts from a tensor hook)
-    bucket = par.GradBucket(all_params, early=[pc._features])
+    # ONE flat bucket for the Gaussian and the deformation gradients, exchanged in three pieces that overlap with the
+    # backward pass: (1) the SH gradients are final when the rasterizer's backward has run (tensor hook), (2) position /
+    # scale / rotation / plane / force_time_embed gradients are final after the deformation backward's data phase and
+    # travel while its weight-gradient products run, (3) the Linear weights and the opacities go at the end.
+    planes = [p for level in deform.deformation_net.grid.grids for p in level]
+    ft = deform.deformation_net.force_time_embed
+    data_params = [pc._xyz, pc._scaling, pc._rotation, *planes, ft.weight, ft.bias]
+    bucket = par.GradBucket(all_params, early=[pc._features, *data_params])
+
+    host_ms = {"shs_hook": 0.0, "data_hook": 0.0, "all_reduce": 0.0, "backward": 0.0, "forward": 0.0}   # debug only
 
     def shs_hook(g):
+        t = time.perf_counter()
         bucket.early_reduce(pc._features, g)
+        host_ms["shs_hook"] += time.perf_counter() - t
 
-    hook = shs_hook if world > 1 else None
+    def data_hook(d_xyz, d_scaling, d_rotation, plane_grads, g_ftw, g_ftb):
+        t = time.perf_counter()
+        bucket.early_reduce_many(data_params, [d_xyz, d_scaling, d_rotation, *plane_grads, g_ftw, g_ftb])
+        host_ms["data_hook"] += time.perf_counter() - t
+
+    hook = shs_hook if dp else None
+    if dp:
+        deform.deformation_net.data_grad_hook = data_hook
 
     def train_step():
+        ta = time.perf_counter()
         image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
         loss = F.l1_loss(image, target)
-        if world > 1:
+        if dp:
             loss = loss / world                           # SUM over ranks == mean over the global batch
+        tb = time.perf_counter()
         loss.backward()
-        if world > 1:
+        tc = time.perf_counter()
+        if dp:
             bucket.all_reduce()
+        host_ms["forward"] += tb - ta
+        host_ms["backward"] += tc - tb
+        host_ms["all_reduce"] += time.perf_counter() - tc
         for p in all_params:
             p.grad = None
 
@@ -197,7 +229,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if dp:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -218,14 +250,18 @@ def main():
     L.gs4d_profile_select(None if args.no_stage_events else dominant.encode())
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     t0 = time.perf_counter()
+    for k in host_ms:
+        host_ms[k] = 0.0
     for i in range(args.steps):
         step()
-        _dbg(f"timed step {i} issued")
+    t_issued = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step; host ms per step in "
+         + ", ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in host_ms.items()))
     _dbg(f"timed region done: {dt / args.steps * 1e3:.3f} ms per step")
     L.gs4d_profile_enable(0)
-    if world > 1:
+    if dp:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -333,12 +369,15 @@ def main():
 
         def opt_step():
             image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
-            loss = F.l1_loss(image, target) + reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
-            if world > 1:
-                loss = loss / world
-            loss.backward()
-            if world > 1:
+            regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
+            if not dp:
+                (F.l1_loss(image, target) + regul).backward()
+            else:
+                # the regularisers see only the (replicated) planes: every rank adds their gradient locally AFTER the
+                # exchange of the render-path gradients ("view-independent"), no communication
+                (F.l1_loss(image, target) / world).backward()
                 bucket.all_reduce()
+                regul.backward()
             opt.step()
             for p in all_params:
                 p.grad = None
@@ -351,7 +390,7 @@ def main():
             opt_step()
         sync()
         dto = time.perf_counter() - t0
-        if world > 1:
+        if dp:
             t = torch.tensor([dto], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dto = float(t.item())
@@ -361,8 +400,10 @@ def main():
                             "step over all parameters (scene/gaussian_model.py:195-206); not the headline metric"}
     if rank == 0:
         out["with_optimizer"] = with_opt
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        if rehearse:
+            out["rehearsal"] = "multi-rank code path in a process group of one rank: not a result"
+        print(json.dumps(out), file=result_out, flush=True)
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -255,6 +255,22 @@ int gs4d_deform_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, 
                          float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in, float* dL_dshs_in,
                          char* workspace, char* scratch, void* stream);
 
+/* The same backward in two phases, for data-parallel callers that want to start exchanging gradients early
+ * (no counterpart in the reference, which has no distributed code; gs4d_deform_backward == both phases):
+ *   GS4D_DEFORM_BWD_DATA     dL_d(points, scales, rotations, shs), the plane gradients and the gradients of
+ *                            force_time_embed (g->planes, g->ft_w, g->ft_b): final when this phase returns
+ *   GS4D_DEFORM_BWD_WEIGHTS  the Linear weight / bias gradients (g->trunk_*, g->head_*); must follow the data
+ *                            phase of the same call arguments, with `scratch` and `workspace` untouched between. */
+#define GS4D_DEFORM_BWD_DATA 1
+#define GS4D_DEFORM_BWD_WEIGHTS 2
+int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P,
+                                const float* points, const float* scales, const float* rotations,
+                                const float* time, const float* force,
+                                const float* dL_dmeans3D, const float* dL_dscales, const float* dL_drotations,
+                                const float* dL_dshs,
+                                float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in, float* dL_dshs_in,
+                                char* workspace, char* scratch, void* stream, int phases);
+
 /* ---- activations + photometric loss (the framework ops between the three kernels groups) ----
  * Replaces, for the hot path, the torch ops of scene/gaussian_model.py:38-43 applied at
  * gaussian_renderer/renderer.py:170-172 (scales = exp, rotations = F.normalize, opacity = sigmoid)

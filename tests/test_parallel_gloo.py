@@ -53,6 +53,29 @@ def _worker(rank, world, port, out):
         assert e.grad.data_ptr() % 16 == 0 and late.grad.data_ptr() % 16 == 0
         e.grad = late.grad = None
     assert be.split == 64 and be.nbytes == (9 + 70) * 4
+    # a group of early parameters in consecutive slots: one all-reduce over their range (padding travels as zeros)
+    e1, e2 = torch.nn.Parameter(torch.zeros(9)), torch.nn.Parameter(torch.zeros(1, 4, 3, 2).contiguous(memory_format=torch.channels_last))
+    e3, late2 = torch.nn.Parameter(torch.zeros(100)), torch.nn.Parameter(torch.zeros(5))
+    bg = par.GradBucket([late2, e1, e2, e3, dead], early=[e1, e2, e3])
+    for step in range(3):
+        g1 = torch.full((9,), float(rank + 1 + step))
+        g2 = (torch.arange(24, dtype=torch.float32).reshape(1, 4, 3, 2) * (rank + 1)).contiguous(memory_format=torch.channels_last)
+        g3 = torch.arange(100, dtype=torch.float32) + rank
+        assert bg.early_reduce(e1, g1) == (step > 0)                      # e1 on its own, then e2 + e3 as a group ...
+        if step < 2:
+            assert bg.early_reduce_many([e2, e3], [g2, g3]) == (step > 0)
+        else:                                                             # ... or only e3: e2 goes at the end, between two early slots
+            assert bg.early_reduce(e3, g3)
+        assert not bg.early_reduce_many([e1, e3], [g1, g3])               # not consecutive: refused, nothing done
+        e1.grad, e2.grad, e3.grad = g1.clone(), g2.clone(), g3.clone()
+        late2.grad = torch.full((5,), float(rank))
+        bg.all_reduce()
+        assert torch.equal(e1.grad, torch.full((9,), float(3 + 2 * step)))
+        assert torch.equal(e2.grad, torch.arange(24, dtype=torch.float32).reshape(1, 4, 3, 2) * 3)
+        assert e2.grad.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(e3.grad, 2 * torch.arange(100, dtype=torch.float32) + 1)
+        assert torch.equal(late2.grad, torch.full((5,), 1.0))
+        e1.grad = e2.grad = e3.grad = late2.grad = None
     if rank == 0:
         open(out, "w").write("ok")
     dist.barrier()
