@@ -187,7 +187,15 @@ def main():
     planes = [p for level in deform.deformation_net.grid.grids for p in level]
     ft = deform.deformation_net.force_time_embed
     data_params = [pc._xyz, pc._scaling, pc._rotation, *planes, ft.weight, ft.bias]
-    bucket = par.GradBucket(all_params, early=[pc._features, *data_params])
+    comm, collectives = None, "torch.distributed"
+    if dp and dist.get_backend() == "nccl" and not os.environ.get("GS4D_BENCH_TORCH_COLLECTIVES"):
+        try:                                    # collective: all ranks succeed or all fall back together
+            comm, collectives = par.RcclComm(dev), "ncclAllReduce on a side stream (parallel.RcclComm)"
+        except RuntimeError as e:
+            print(f"[bench rank {rank}] direct RCCL communicator unavailable, using torch.distributed collectives: {e}", file=sys.stderr)
+    _dbg(f"gradient exchange through {collectives}")
+    bucket = par.GradBucket(all_params, early=[pc._features, *data_params], comm=comm)
+    dp_hooks = os.environ.get("GS4D_BENCH_DP_HOOKS", "all")       # experiments: "all" | "shs" | "none"
 
     host_ms = {"shs_hook": 0.0, "data_hook": 0.0, "all_reduce": 0.0, "backward": 0.0, "forward": 0.0}   # debug only
 
@@ -201,8 +209,8 @@ def main():
         bucket.early_reduce_many(data_params, [d_xyz, d_scaling, d_rotation, *plane_grads, g_ftw, g_ftb])
         host_ms["data_hook"] += time.perf_counter() - t
 
-    hook = shs_hook if dp else None
-    if dp:
+    hook = shs_hook if dp and dp_hooks in ("all", "shs") else None
+    if dp and dp_hooks == "all":
         deform.deformation_net.data_grad_hook = data_hook
 
     def train_step():
@@ -347,7 +355,7 @@ def main():
                                    f"1 view per GPU per step", "global_batch_views": world,
                        "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
                        "log_s0_offset": round(log_s0_offset, 4),
-                       "grad_allreduce_bytes": bucket.nbytes},
+                       "grad_allreduce_bytes": bucket.nbytes, "collectives": collectives if dp else None},
             "roofline": roofline, "cpu_baseline": cpu,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
@@ -405,6 +413,8 @@ def main():
         print(json.dumps(out), file=result_out, flush=True)
     if dp:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

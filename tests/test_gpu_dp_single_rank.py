@@ -14,7 +14,8 @@ from oracle import deformation_ref as R
 pytestmark = pytest.mark.gpu
 
 
-def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path):
+@pytest.mark.parametrize("direct", [False, True], ids=["torch_collectives", "rccl_direct"])
+def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path, direct):
     RD, F, syn, par = pkg("renderer"), pkg("fused"), pkg("synthetic"), pkg("parallel")
     cfg = R.DeformConfig(plane_channels=16, resolution=[16, 16, 16, 8], multires=[1, 2])
     torch.manual_seed(5)
@@ -40,7 +41,8 @@ def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path):
     dist.init_process_group("nccl", init_method="file://" + str(tmp_path / "rendezvous"), rank=0, world_size=1)
     par.GradBucket.exchange_in_world_of_one = True
     try:
-        bucket = par.GradBucket(params, early=[pc._features, *data_params])
+        comm = par.RcclComm(dev) if direct else None          # ncclAllReduce on a side stream vs dist.all_reduce
+        bucket = par.GradBucket(params, early=[pc._features, *data_params], comm=comm)
         started = []
         net.data_grad_hook = lambda d_xyz, d_sc, d_rot, gp, gw, gb: started.append(
             bucket.early_reduce_many(data_params, [d_xyz, d_sc, d_rot, *gp, gw, gb]))
@@ -51,6 +53,11 @@ def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path):
             F.l1_loss(image, target).backward()
             assert started == [step > 0, step > 0]                 # SH hook first, then the data phase
             bucket.all_reduce()
+            if step == 1 and direct:                               # the exchange really ran: poison check through a sum
+                probe = torch.full((1000,), 2.0, device=dev)
+                comm.all_reduce_sum(probe)
+                comm.wait()
+                assert float(probe.sum()) == 2000.0                # one rank: SUM leaves the values as they are
             torch.cuda.synchronize()
             lo, hi = bucket.flat.data_ptr(), bucket.flat.data_ptr() + 4 * bucket.flat.numel()
             for p, w in zip(params, want):
@@ -69,4 +76,6 @@ def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path):
     finally:
         net.data_grad_hook = None
         par.GradBucket.exchange_in_world_of_one = False
+        if direct and "comm" in locals() and comm is not None:
+            comm.close()
         dist.destroy_process_group()
