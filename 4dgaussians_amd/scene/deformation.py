@@ -57,6 +57,59 @@ def init_zero_(model):
                 init.zeros_(m.bias)
 
 
+class _Plan:
+    """What a parameter set fixes from step to step, built once: the filled gs4d_deform_desc, and the layout of the
+    ONE allocation that receives every parameter gradient (offsets, the gs4d_deform_grads words to patch, shape /
+    stride / offset of each gradient view).  A step then costs a pointer comparison instead of ~50 tensor
+    conversions and ~100 ctypes field assignments in each direction -- host time that sits on the critical path
+    after the rasterizer's host synchronisation.  Valid while every parameter keeps its storage (`matches`)."""
+
+    def __init__(self, cfg, params):
+        import numpy as np
+        self.params = list(params)
+        self.ptrs = [p.data_ptr() for p in self.params]
+        n_planes = cfg["L"] * 6
+        planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in self.params])
+        # the fast path needs every parameter to be usable in place (float32, dense, planes channels-last)
+        self.in_place = all(a.data_ptr() == b.data_ptr() and a.dtype == torch.float32
+                            for a, b in zip(planes + [aabb, ft_w, ft_b] + trunk + heads, self.params))
+        self.desc = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
+        self.n_planes, self.n_trunk = n_planes, len(trunk)
+        # gradient allocation: planes as [H][W][C] memory under the [1,C,H,W] shape, everything else row-major
+        views, offs, total = [], [], 0
+        for t in planes + [ft_w, ft_b] + trunk + heads:
+            n = t.numel()
+            if t.dim() == 4:
+                _, c, h, w = t.shape
+                views.append((tuple(t.shape), (h * w * c, 1, w * c, c), total))
+            else:
+                views.append((tuple(t.shape), tuple(t.contiguous().stride()), total))
+            offs.append(total)
+            total += (n + 63) // 64 * 64
+        self.grad_views, self.grad_total = views, max(total, 1)
+        # the words of gs4d_deform_grads (all 8-byte pointers) in the order of `views`
+        self.grads = DeformGrads()
+        words = np.frombuffer(memoryview(self.grads).cast("B"), dtype=np.uint64)
+        field = {name: getattr(DeformGrads, name).offset // 8 for name, _ in DeformGrads._fields_}
+        idx = [field["planes"] + i for i in range(n_planes)] + [field["ft_w"], field["ft_b"]]
+        for i in range(len(trunk) // 2):
+            idx += [field["trunk_w"] + i, field["trunk_b"] + i]
+        for h in range(4):
+            idx += [field["head_w1"] + h, field["head_b1"] + h, field["head_w2"] + h, field["head_b2"] + h]
+        self._words, self._idx = words, np.asarray(idx, dtype=np.int64)
+        self._byte_offs = np.asarray(offs, dtype=np.uint64) * np.uint64(4)
+
+    def matches(self, params) -> bool:
+        return len(params) == len(self.ptrs) and all(p.data_ptr() == q for p, q in zip(params, self.ptrs))
+
+    def new_grads(self, device):
+        """-> (gs4d_deform_grads pointing into a fresh zero-filled allocation, the gradient views in parameter order)."""
+        import numpy as np
+        flat = torch.zeros(self.grad_total, dtype=torch.float32, device=device)
+        self._words[self._idx] = np.uint64(flat.data_ptr()) + self._byte_offs
+        return self.grads, [torch.as_strided(flat, shp, st, off) for shp, st, off in self.grad_views]
+
+
 class _DeformFunction(torch.autograd.Function):
     """points, scales, rotations, shs, time, force, cfg, n_planes, *params -> 4 outputs.
     params = planes..., aabb, ft_w, ft_b, trunk (w,b)..., heads (w1,b1,w2,b2) x 4."""
@@ -104,8 +157,13 @@ class _DeformFunction(torch.autograd.Function):
             rot_ = rot_.clone()
         if shs_.data_ptr() % 16:
             shs_ = shs_.clone()
-        planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
-        d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
+        plan = cfg.get("plan")
+        if plan is not None and plan.in_place and plan.matches(params):
+            d = plan.desc
+        else:
+            plan = None
+            planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
+            d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
         d.no_grad = 0 if any(ctx.needs_input_grad) else 1      # under torch.no_grad() nothing will read the activations
         o_xyz, o_sc, o_rot, o_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, shs_))
         ws = torch.empty(max(int(L.gs4d_deform_workspace_bytes(C.byref(d), C.c_int(P))), 256), dtype=torch.uint8, device=dev)
@@ -116,7 +174,14 @@ class _DeformFunction(torch.autograd.Function):
                                        _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_deform_forward")
         ctx.cfg = cfg
-        ctx.save_for_backward(points_, scales_, rot_, time_, force_, ws, *params)
+        ctx.plan = plan
+        if plan is not None:
+            # the parameters are not re-read through saved_tensors (50 unpacks per step); their versions are kept
+            # instead, so that an in-place update between forward and backward is still refused
+            ctx.versions = [p._version for p in params]
+            ctx.save_for_backward(points_, scales_, rot_, time_, force_, ws)
+        else:
+            ctx.save_for_backward(points_, scales_, rot_, time_, force_, ws, *params)
         return o_xyz, o_sc, o_rot, o_shs
 
     @staticmethod
@@ -126,25 +191,35 @@ class _DeformFunction(torch.autograd.Function):
         points_, scales_, rot_, time_, force_, ws, *params = ctx.saved_tensors
         dev = points_.device
         P = points_.shape[0]
-        planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
-        d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
-        # every parameter gradient lives in one allocation cleared by one fill; plane gradients are
-        # channels-last like the planes themselves ([H][W][C] bytes under a [1,C,H,W] shape)
-        nhwc = [(1, p.shape[2], p.shape[3], p.shape[1]) for p in planes]
-        flat = _cabi.zeros_group(dev, *nhwc, ft_w.shape, ft_b.shape, *[t.shape for t in trunk], *[t.shape for t in heads])
-        gp = [t.permute(0, 3, 1, 2) for t in flat[:len(planes)]]
-        g_ftw, g_ftb = flat[len(planes)], flat[len(planes) + 1]
-        gt = flat[len(planes) + 2:len(planes) + 2 + len(trunk)]
-        gh = flat[len(planes) + 2 + len(trunk):]
-        g = DeformGrads()
-        for i, t in enumerate(gp):
-            g.planes[i] = t.data_ptr()
-        g.ft_w, g.ft_b = g_ftw.data_ptr(), g_ftb.data_ptr()
-        for i in range(len(trunk) // 2):
-            g.trunk_w[i], g.trunk_b[i] = gt[2 * i].data_ptr(), gt[2 * i + 1].data_ptr()
-        for h in range(4):
-            g.head_w1[h], g.head_b1[h] = gh[4 * h].data_ptr(), gh[4 * h + 1].data_ptr()
-            g.head_w2[h], g.head_b2[h] = gh[4 * h + 2].data_ptr(), gh[4 * h + 3].data_ptr()
+        plan = ctx.plan
+        if plan is not None:
+            if [p._version for p in plan.params] != ctx.versions:
+                raise RuntimeError("a deformation parameter was modified in place between forward and backward")
+            d = plan.desc
+            g, views = plan.new_grads(dev)
+            n_pl, n_tr = plan.n_planes, plan.n_trunk
+            gp, g_ftw, g_ftb = views[:n_pl], views[n_pl], views[n_pl + 1]
+            gt, gh = views[n_pl + 2:n_pl + 2 + n_tr], views[n_pl + 2 + n_tr:]
+        else:
+            planes, aabb, ft_w, ft_b, trunk, heads = _DeformFunction._split(cfg, [p.detach() for p in params])
+            d = _DeformFunction._desc(cfg, planes, aabb, ft_w, ft_b, trunk, heads)
+            # every parameter gradient lives in one allocation cleared by one fill; plane gradients are
+            # channels-last like the planes themselves ([H][W][C] bytes under a [1,C,H,W] shape)
+            nhwc = [(1, p.shape[2], p.shape[3], p.shape[1]) for p in planes]
+            flat = _cabi.zeros_group(dev, *nhwc, ft_w.shape, ft_b.shape, *[t.shape for t in trunk], *[t.shape for t in heads])
+            gp = [t.permute(0, 3, 1, 2) for t in flat[:len(planes)]]
+            g_ftw, g_ftb = flat[len(planes)], flat[len(planes) + 1]
+            gt = flat[len(planes) + 2:len(planes) + 2 + len(trunk)]
+            gh = flat[len(planes) + 2 + len(trunk):]
+            g = DeformGrads()
+            for i, t in enumerate(gp):
+                g.planes[i] = t.data_ptr()
+            g.ft_w, g.ft_b = g_ftw.data_ptr(), g_ftb.data_ptr()
+            for i in range(len(trunk) // 2):
+                g.trunk_w[i], g.trunk_b[i] = gt[2 * i].data_ptr(), gt[2 * i + 1].data_ptr()
+            for h in range(4):
+                g.head_w1[h], g.head_b1[h] = gh[4 * h].data_ptr(), gh[4 * h + 1].data_ptr()
+                g.head_w2[h], g.head_b2[h] = gh[4 * h + 2].data_ptr(), gh[4 * h + 3].data_ptr()
         gz = lambda t, like: (torch.zeros_like(like) if t is None else (t if t.dtype == torch.float32 and t.is_contiguous() else t.to(torch.float32).contiguous()))
         g_xyz, g_sc, g_rot = gz(g_xyz, points_), gz(g_sc, scales_), gz(g_rot, rot_)
         g_shs = gz(g_shs, torch.empty(P, 16, 3, device=dev))
@@ -174,7 +249,7 @@ class _DeformFunction(torch.autograd.Function):
             run(BWD_DATA)
             hook(d_xyz, d_sc, d_rot, gp, g_ftw, g_ftb)
             run(BWD_WEIGHTS)
-        param_grads = gp + [None, g_ftw, g_ftb] + gt + gh
+        param_grads = list(gp) + [None, g_ftw, g_ftb] + list(gt) + list(gh)
         return (d_xyz, d_sc, d_rot, d_shs, None, None, None, *param_grads)
 
 
@@ -266,10 +341,27 @@ class Deformation(nn.Module):
             heads += [h[1].weight, h[1].bias, h[3].weight, h[3].bias]
         return planes + [self.grid.aabb, self.force_time_embed.weight, self.force_time_embed.bias] + trunk + heads
 
+    def __getstate__(self):                        # the step cache holds ctypes structures: never pickled / deep-copied
+        state = dict(super().__getstate__()) if hasattr(super(), "__getstate__") else dict(self.__dict__)
+        state.pop("_step_cache", None)
+        return state
+
+    def _apply(self, fn, *a, **k):                 # .to() / .cuda() / .float(): parameters may get new storage
+        self._step_cache = None
+        return super()._apply(fn, *a, **k)
+
     def forward_dynamic(self, points, scales, rotations, opacity, shs, time, force, prev_frames=None):
         if prev_frames is not None:
             raise NotImplementedError("prev_frames conditioning is outside the hot path (SURVEY.md section 8)")
-        out = _DeformFunction.apply(points, scales, rotations, shs, time, force, self._config(), *self._params())
+        cache = self.__dict__.get("_step_cache")
+        if cache is None or not cache[1]["plan"].matches(cache[0]):
+            params = self._params()
+            cfg = self._config()
+            cfg["plan"] = _Plan(cfg, params)
+            cache = self.__dict__["_step_cache"] = (params, cfg)
+        params, cfg = cache
+        cfg["data_grad_hook"] = self.data_grad_hook
+        out = _DeformFunction.apply(points, scales, rotations, shs, time, force, cfg, *params)
         return out[0], out[1], out[2], opacity[:, :1], out[3]
 
     def get_mlp_parameters(self):
