@@ -1,0 +1,143 @@
+"""The k-nearest-neighbour rigidity / momentum regularisers of the fine stage:
+gaussian_renderer/renderer.py:151-203 of the reference, computed from the three deformation queries of a view
+(t - dt, t, t + dt) and the k = min(100, n) nearest neighbours of the deformed positions.
+
+`neighbor_diff_norm(x, idx)` is the reference's `torch.norm(x[idx] - x[None, :, None], p=2, dim=-1)` as one kernel per
+direction (csrc/rigidity.hip: no (n, k, dim) intermediates); `temporal_regulation` / `recurrent_regulation` assemble
+the dictionaries of the two branches with the reference's expressions, term for term.  There is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _cabi
+from .pointops import knn
+
+
+def transpose_graph(idx: torch.Tensor):
+    """idx (..., n, k) -> (order int32 [n*k], row_start int32 [n+1]): the pairs i*k+s sorted by their target idx[i][s]
+    and where each target's pairs begin.  Built once per neighbour graph (one device sort, shared by every term of a
+    view); it turns the backward's scatter into a gather."""
+    n, k = idx.shape[-2], idx.shape[-1]
+    if n * k >= 2 ** 31:
+        raise RuntimeError("transpose_graph: n * k must stay below 2^31")
+    flat = idx.reshape(-1).to(torch.int32)
+    if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= n):
+        raise RuntimeError("transpose_graph: neighbour index out of range")
+    _, order = torch.sort(flat)
+    counts = torch.bincount(flat, minlength=n)[:n]
+    row_start = torch.zeros(n + 1, dtype=torch.int32, device=idx.device)
+    row_start[1:] = torch.cumsum(counts, 0)
+    return order.to(torch.int32), row_start
+
+
+class _NeighborDiffNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, graph_t):
+        if x.device.type != "cuda":
+            raise RuntimeError("neighbor_diff_norm runs on a HIP device only; there is no CPU path")
+        n, dim = x.shape
+        k = idx.shape[-1]
+        x_ = x.detach().to(torch.float32).contiguous()
+        idx_ = idx.reshape(n, k).to(torch.int64).contiguous()
+        d = torch.empty((n, k), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            rc = _cabi.lib().gs4d_neighbor_diff_norm_forward(C.c_int(n), C.c_int(k), C.c_int(dim), _cabi.ptr(x_), _cabi.ptr(idx_),
+                                                             _cabi.ptr(d), _cabi.current_stream(x.device))
+        _cabi.check(rc, "gs4d_neighbor_diff_norm_forward")
+        ctx.save_for_backward(x_, idx_, d)
+        ctx.graph_t = graph_t
+        return d
+
+    @staticmethod
+    def backward(ctx, g):
+        x_, idx_, d = ctx.saved_tensors
+        n, dim = x_.shape
+        k = idx_.shape[1]
+        g_ = g.to(torch.float32).contiguous()
+        dx = torch.zeros_like(x_)
+        L = _cabi.lib()
+        with torch.cuda.device(x_.device):
+            if ctx.graph_t is None:                             # float atomics (no transposed graph at hand)
+                rc = L.gs4d_neighbor_diff_norm_backward(C.c_int(n), C.c_int(k), C.c_int(dim), _cabi.ptr(x_), _cabi.ptr(idx_),
+                                                        _cabi.ptr(d), _cabi.ptr(g_), _cabi.ptr(dx),
+                                                        _cabi.current_stream(x_.device))
+            else:
+                order, row_start = ctx.graph_t
+                coef = torch.empty_like(d)
+                rc = L.gs4d_neighbor_diff_norm_backward_gather(
+                    C.c_int(n), C.c_int(k), C.c_int(dim), _cabi.ptr(x_), _cabi.ptr(idx_), _cabi.ptr(d), _cabi.ptr(g_),
+                    _cabi.ptr(order), _cabi.ptr(row_start), _cabi.ptr(coef), _cabi.ptr(dx), _cabi.current_stream(x_.device))
+        _cabi.check(rc, "gs4d_neighbor_diff_norm_backward")
+        return dx, None, None
+
+
+def neighbor_diff_norm(x: torch.Tensor, idx: torch.Tensor, graph_t=None) -> torch.Tensor:
+    """x (n, 3 | 4), idx (..., n, k) integer rows of neighbour indices into x -> distances shaped like idx:
+    out[..., i, s] = || x[idx[..., i, s]] - x[i] ||_2, differentiable in x (zero distance -> zero gradient).
+    graph_t = transpose_graph(idx), when given, makes the backward a deterministic gather instead of float atomics
+    (worth building as soon as two terms share the neighbour lists)."""
+    if x.dim() != 2 or x.shape[1] not in (3, 4):
+        raise RuntimeError("neighbor_diff_norm: x must be (n, 3) or (n, 4)")
+    if idx.shape[-2] != x.shape[0] or idx.numel() != x.shape[0] * idx.shape[-1]:
+        raise RuntimeError("neighbor_diff_norm: idx must hold one row of neighbours per row of x")
+    return _NeighborDiffNorm.apply(x, idx, graph_t).view(idx.shape)
+
+
+def _neighbours(means3D_final, k):
+    n = means3D_final.shape[0]
+    k = min(int(k), n)
+    p = means3D_final[None].contiguous().detach()
+    idx, dist = knn(p, p, k)                               # renderer.py:161 / :192
+    return k, n, idx, torch.exp(-100 * dist), transpose_graph(idx)     # weight: renderer.py:162 / :193
+
+
+def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scales_final, scales_prev, scales_nxt,
+                        shs_final, shs_prev, shs_nxt, rotations_final, rotations_prev, rotations_next, k=100):
+    """The non-recurrent branch, renderer.py:173-203.  *_final / *_prev / *_nxt: the deformation at t, t - dt, t + dt
+    (scales activated as at :145,:181-182; rotations_final activated as at :146, rotations_prev / _next as the
+    deformation returns them, exactly as the reference mixes them); means3D: the undeformed positions."""
+    reg = {}
+    momentum_all = torch.abs(means3D_nxt + means3D_prev - 2 * means3D_final)
+    reg["momentum"] = momentum_all.mean()
+    reg["scales"] = torch.abs(scales_nxt + scales_prev - 2 * scales_final).sum(dim=1).mean()
+    reg["shs"] = torch.abs(shs_nxt + shs_prev - 2 * shs_final).mean()
+    vel_xyz = (means3D_nxt - means3D_final) / 2
+    vel_long = means3D_nxt - means3D
+    k, n, idx, weight, gt = _neighbours(means3D_final, k)
+    mom_xyz_dist = neighbor_diff_norm(vel_xyz, idx, gt)
+    mom_long_dist = neighbor_diff_norm(vel_long, idx, gt)
+    reg["knn_xyz"] = (weight * mom_xyz_dist).sum() / k / n
+    reg["knn_long"] = (weight * torch.abs(mom_long_dist - mom_xyz_dist)).sum() / k / n
+    rot_v1 = rotations_final - rotations_prev
+    rot_v2 = rotations_next - rotations_final
+    mom_rot_dist1 = neighbor_diff_norm(rot_v1, idx, gt)
+    mom_rot_dist2 = neighbor_diff_norm(rot_v2, idx, gt)
+    # :203 as written: the MEAN of the rotation term scales the sum of the weights
+    reg["knn_rot"] = (weight * (mom_rot_dist1 + mom_rot_dist2).mean()).sum() / k / n
+    return reg
+
+
+def recurrent_regulation(means3D_in, means3D_canonical, means3D_final, rotations_in, rotations_final, scales_in,
+                         scales_final, shs_in, shs_final, k=100):
+    """The recurrent branch, renderer.py:154-171: *_in is the previous frame's state fed to the deformation,
+    means3D_canonical is pc.get_xyz."""
+    reg = {}
+    vel_xyz = means3D_final - means3D_in
+    vel_long = means3D_final - means3D_canonical
+    vel_rot = rotations_final - rotations_in
+    vel_scale = scales_final - scales_in
+    vel_shs = shs_final - shs_in
+    k, n, idx, weight, gt = _neighbours(means3D_final, k)
+    mom_xyz_dist = neighbor_diff_norm(vel_xyz, idx, gt)
+    mom_long_dist = neighbor_diff_norm(vel_long, idx, gt)
+    mom_rot_dist = neighbor_diff_norm(vel_rot, idx, gt)
+    reg["knn_xyz"] = (weight * mom_xyz_dist).sum() / k / n
+    reg["knn_long"] = (weight * torch.abs(mom_long_dist - mom_xyz_dist)).sum() / k / n
+    reg["knn_rot"] = (weight * mom_rot_dist).sum() / k / n
+    reg["momentum"] = vel_xyz.abs().sum(dim=1).mean()
+    reg["scales"] = vel_scale.abs().sum(dim=1).mean()
+    reg["shs"] = vel_shs.mean()
+    return reg

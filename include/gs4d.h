@@ -338,6 +338,22 @@ int gs4d_plane_reg_forward(int nterms, const gs4d_plane_reg_term* terms /* host 
 int gs4d_plane_reg_backward(int nterms, const gs4d_plane_reg_term* terms /* host array */, const float* g_loss,
                             void* stream);
 
+/* ---- rigidity regulariser building block (with gs4d_knn_query) ----
+ * d[i][s] = || x[idx[i][s]] - x[i] ||_2: the reference's torch.norm(vel[idx] - vel[None, :, None], p=2, dim=-1)
+ * (gaussian_renderer/renderer.py:163-165,194-195,201-202) without the gathered (n, k, dim) intermediates.
+ * x [n, dim] float (dim 3 or 4), idx [n, k] int64 rows of neighbour indices into x (as utils/general_utils.py:144-158
+ * returns them), d [n, k].  backward: g [n, k] = dL/dd; dx [n, dim] must be zero-filled (or hold a gradient to add
+ * to) -- it is accumulated with float atomics; pairs with d == 0 contribute nothing (torch.norm's subgradient). */
+int gs4d_neighbor_diff_norm_forward(int n, int k, int dim, const float* x, const long long* idx, float* d, void* stream);
+int gs4d_neighbor_diff_norm_backward(int n, int k, int dim, const float* x, const long long* idx, const float* d,
+                                     const float* g, float* dx, void* stream);
+/* The same backward without atomics, given the transposed neighbour graph: order [n*k] int32 = the pair indices
+ * i*k+s sorted by idx[i][s], row_start [n+1] int32 = first position in `order` of the pairs that point at each row;
+ * coef_scratch [n*k] floats.  dx is ADDED to (plain stores, one wave per row): deterministic.  n*k < 2^31. */
+int gs4d_neighbor_diff_norm_backward_gather(int n, int k, int dim, const float* x, const long long* idx, const float* d,
+                                            const float* g, const int* order, const int* row_start, float* coef_scratch,
+                                            float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

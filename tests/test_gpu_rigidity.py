@@ -1,0 +1,117 @@
+"""k-NN rigidity / momentum regularisers: gs4d_neighbor_diff_norm_* and the two dictionaries of
+gaussian_renderer/renderer.py:151-203 against the CPU restatement (oracle/rigidity_ref.py: the reference's torch
+expressions with an exact brute-force neighbour search).  Tolerances: values 1e-5 relative, gradients 2e-5 of the
+tensor's largest entry (float32 sums over n*k pairs in a different order)."""
+import pytest
+import torch
+
+from conftest import pkg
+from oracle import rigidity_ref as RR
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("means3D", "means3D_final", "means3D_prev", "means3D_nxt", "scales_final", "scales_prev", "scales_nxt",
+         "shs_final", "shs_prev", "shs_nxt", "rotations_final", "rotations_prev", "rotations_next")
+
+
+def _scene(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, scale=1.0: torch.randn(*s, generator=g) * scale
+    base = r(n, 3, scale=0.05)                                 # dense cloud: exp(-100 d) weights are not all ~0
+    t = {"means3D": base}
+    for name in ("means3D_final", "means3D_prev", "means3D_nxt"):
+        t[name] = base + r(n, 3, scale=0.01)
+    for name in ("scales_final", "scales_prev", "scales_nxt"):
+        t[name] = torch.exp(r(n, 3, scale=0.3) - 3)
+    for name in ("shs_final", "shs_prev", "shs_nxt"):
+        t[name] = r(n, 16, 3, scale=0.2)
+    for name in ("rotations_final", "rotations_prev", "rotations_next"):
+        t[name] = r(n, 4)
+    return t
+
+
+@pytest.mark.parametrize("gather", [False, True], ids=["atomics", "transposed_graph"])
+@pytest.mark.parametrize("dim", [3, 4])
+def test_neighbor_diff_norm_matches_torch_expression(dim, gather):
+    rig = pkg("rigidity")
+    n, k = 700, 100
+    g = torch.Generator().manual_seed(dim)
+    x = torch.randn(n, dim, generator=g)
+    idx = torch.randint(0, n, (1, n, k), generator=g)
+    idx[0, :, 0] = torch.arange(n)                             # every point is its own first neighbour: distance 0
+    up = torch.randn(1, n, k, generator=g)
+    xc = x.clone().requires_grad_(True)
+    want = RR.neighbor_diff_norm(xc, idx)
+    (want * up).sum().backward()
+    xg = x.cuda().requires_grad_(True)
+    graph_t = rig.transpose_graph(idx.cuda()) if gather else None
+    if gather:
+        order, row_start = graph_t
+        assert order.dtype == torch.int32 and row_start.dtype == torch.int32 and int(row_start[-1]) == n * k
+        assert torch.equal(torch.sort(order.long()).values.cpu(), torch.arange(n * k))          # a permutation of the pairs
+        tgt = idx.reshape(-1)[order.long().cpu()]
+        assert bool((tgt[1:] >= tgt[:-1]).all())                                                 # grouped by target
+    got = rig.neighbor_diff_norm(xg, idx.cuda(), graph_t)
+    assert got.shape == (1, n, k)
+    (got * up.cuda()).sum().backward()
+    assert torch.allclose(got.cpu(), want.detach(), rtol=1e-6, atol=1e-7)
+    assert float(got.detach()[0, :, 0].abs().max()) == 0.0
+    assert torch.isfinite(xg.grad).all()
+    assert float((xg.grad.cpu() - xc.grad).abs().max()) <= 2e-5 * float(xc.grad.abs().max())
+
+
+def test_neighbor_diff_norm_edge_cases():
+    rig = pkg("rigidity")
+    x = torch.randn(5, 3, device="cuda", requires_grad=True)
+    idx = torch.zeros(1, 5, 1, dtype=torch.int64, device="cuda")               # k = 1
+    d = rig.neighbor_diff_norm(x, idx)
+    assert torch.allclose(d[0, :, 0], torch.norm(x.detach()[0][None] - x.detach(), dim=-1), atol=1e-7)
+    d.sum().backward()
+    assert torch.isfinite(x.grad).all()
+    empty = rig.neighbor_diff_norm(torch.zeros(0, 3, device="cuda"), torch.zeros(1, 0, 4, dtype=torch.int64, device="cuda"))
+    assert empty.shape == (1, 0, 4)
+    with pytest.raises(RuntimeError):
+        rig.transpose_graph(torch.full((1, 5, 2), 5, dtype=torch.int64, device="cuda"))          # index out of range
+    with pytest.raises(RuntimeError):
+        rig.neighbor_diff_norm(torch.zeros(4, 5, device="cuda"), idx)
+    with pytest.raises(RuntimeError):
+        rig.neighbor_diff_norm(torch.zeros(4, 3), torch.zeros(1, 4, 2, dtype=torch.int64))     # CPU tensors: no CPU path
+
+
+def test_temporal_regulation_matches_reference_expressions():
+    rig = pkg("rigidity")
+    n, k = 600, 100
+    cpu = {a: v.clone().requires_grad_(True) for a, v in _scene(n, 7).items()}
+    idx, dist = RR.knn_bruteforce(cpu["means3D_final"].detach(), k)
+    want = RR.temporal_regulation(*[cpu[a] for a in NAMES], idx, dist)
+    sum(want.values()).backward()
+    dev = {a: v.detach().clone().cuda().requires_grad_(True) for a, v in cpu.items()}
+    got = rig.temporal_regulation(*[dev[a] for a in NAMES], k=k)
+    sum(got.values()).backward()
+    assert set(got) == set(want) == {"momentum", "scales", "shs", "knn_xyz", "knn_long", "knn_rot"}
+    for key in want:
+        assert abs(float(got[key]) - float(want[key])) <= 1e-5 * abs(float(want[key])) + 1e-9, key
+    for a in NAMES:
+        if cpu[a].grad is None:
+            assert dev[a].grad is None or float(dev[a].grad.abs().max()) == 0.0, a
+            continue
+        assert float((dev[a].grad.cpu() - cpu[a].grad).abs().max()) <= 2e-5 * float(cpu[a].grad.abs().max()) + 1e-12, a
+
+
+def test_recurrent_regulation_and_small_clouds():
+    rig = pkg("rigidity")
+    n = 40                                                      # fewer points than k: k = min(100, n), renderer.py:160
+    g = torch.Generator().manual_seed(3)
+    t = [torch.randn(n, 3, generator=g) * 0.05 for _ in range(3)] + [torch.randn(n, 4, generator=g) for _ in range(2)] + \
+        [torch.rand(n, 3, generator=g) for _ in range(2)] + [torch.randn(n, 16, 3, generator=g) for _ in range(2)]
+    cpu = [v.clone().requires_grad_(True) for v in t]
+    idx, dist = RR.knn_bruteforce(cpu[2].detach(), n)
+    want = RR.recurrent_regulation(*cpu, idx, dist)
+    sum(want.values()).backward()
+    dev = [v.clone().cuda().requires_grad_(True) for v in t]
+    got = rig.recurrent_regulation(*dev, k=100)
+    sum(got.values()).backward()
+    for key in want:
+        assert abs(float(got[key]) - float(want[key])) <= 1e-5 * abs(float(want[key])) + 1e-9, key
+    for a, b in zip(dev, cpu):
+        assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-12
