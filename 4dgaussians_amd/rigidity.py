@@ -26,10 +26,9 @@ def transpose_graph(idx: torch.Tensor):
     flat = idx.reshape(-1).to(torch.int32)
     if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= n):
         raise RuntimeError("transpose_graph: neighbour index out of range")
-    _, order = torch.sort(flat)
-    counts = torch.bincount(flat, minlength=n)[:n]
-    row_start = torch.zeros(n + 1, dtype=torch.int32, device=idx.device)
-    row_start[1:] = torch.cumsum(counts, 0)
+    targets, order = torch.sort(flat)
+    # where each target's run begins in the sorted list (a bincount + cumsum costs more than the sort itself)
+    row_start = torch.searchsorted(targets, torch.arange(n + 1, dtype=torch.int32, device=idx.device)).to(torch.int32)
     return order.to(torch.int32), row_start
 
 
