@@ -2,7 +2,8 @@
 render() (:82-221) and render_for_image() (:258-329) restricted to what SURVEY.md section 8 puts
 in scope -- settings, one deformation query, the three activations
 (scene/gaussian_model.py:38-43: exp / L2-normalise / sigmoid) and the rasterizer call.  The
-fork-specific regularisers (two extra deformation queries + the k=100 kNN) are "next" rows.
+fork-specific regularisers (two extra deformation queries + the k=100 kNN, :173-203) are a "next" row:
+`render(..., regularise=True)` adds them (rigidity.py) and returns the reference's 7-tuple.
 
 Host-side plumbing only: all compute happens in libgs4d.so through the two drop-in modules.
 """
@@ -43,10 +44,17 @@ class Camera:
         self.time, self.force = float(time), float(force)
 
 
+MAX_FRAME = 25                                   # scene/dataset_readers.py:30: the regulariser's time step is 1 / (MAX_FRAME - 1)
+
+
 def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
-           scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False, shs_grad_hook=None):
+           scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False, shs_grad_hook=None,
+           regularise: bool = False, max_frame: int = MAX_FRAME):
     """-> (image, screenspace_points, visibility_filter, radii, depth), as the first five items of the
-    reference's 7-tuple (renderer.py:221).  shs_grad_hook(grad), if given, is called during the backward pass as soon
+    reference's 7-tuple (renderer.py:221); with regularise=True the full 7-tuple (..., reg_dict, None): reg_dict holds
+    the fine stage's momentum / scales / shs / knn_xyz / knn_long / knn_rot terms (:173-203; empty in the coarse
+    stage, :152-153), computed from the deformation at t - dt and t + dt -- ONE batched query of 2 P points here,
+    two calls in the reference -- and the k = min(100, P) nearest neighbours of the deformed positions.  shs_grad_hook(grad), if given, is called during the backward pass as soon
     as dL/d(deformed SH coefficients) exists, i.e. before the deformation backward runs (data-parallel training
     starts the all-reduce of the SH gradients there, parallel.GradBucket.early_reduce)."""
     screenspace_points = torch.zeros_like(pc._xyz, requires_grad=torch.is_grad_enabled())
@@ -69,9 +77,28 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
                                                                           time, force, None)
         if shs_grad_hook is not None and shs.requires_grad:
             shs.register_hook(shs_grad_hook)
+    raw_inputs = (pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features if hasattr(pc, "_features") else None)
     scales, rotations, opacity = activate(scales, rotations, opacity)    # exp / L2-normalise / sigmoid, one kernel
+    reg_dict = {}
+    if regularise and "coarse" not in stage and deform is not None:
+        from .rigidity import temporal_regulation
+        n = pc._xyz.shape[0]
+        dt = 1.0 / (max_frame - 1)
+        xyz0, sc0, rot0, op0, shs0 = raw_inputs
+        if shs0 is None:
+            shs0 = pc.get_features
+        two = lambda t: torch.cat([t, t], dim=0)
+        times = torch.cat([torch.full((n, 1), cam.time - dt, dtype=torch.float32, device=xyz0.device),
+                           torch.full((n, 1), cam.time + dt, dtype=torch.float32, device=xyz0.device)], dim=0)
+        forces = torch.full((2 * n, 1), cam.force, dtype=torch.float32, device=xyz0.device)
+        m2, s2, r2, _, h2 = deform.forward_dynamic(two(xyz0), two(sc0), two(rot0), two(op0), two(shs0), times, forces, None)
+        s2 = torch.exp(s2)                                               # pc.scaling_activation, renderer.py:181-182
+        reg_dict = temporal_regulation(xyz0, means3D, m2[:n], m2[n:], scales, s2[:n], s2[n:], shs, h2[:n], h2[n:],
+                                       rotations, r2[:n], r2[n:])
     image, radii, depth = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
                                      opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+    if regularise:
+        return image, screenspace_points, radii > 0, radii, depth, reg_dict, None
     return image, screenspace_points, radii > 0, radii, depth
 
 

@@ -406,8 +406,52 @@ def main():
                     "ms_per_step": round(dto / args.steps * 1e3, 4),
                     "note": "same iteration + HexPlane grid regularisers (scene/gaussian_model.py:679-706) + one fused AdamW "
                             "step over all parameters (scene/gaussian_model.py:195-206); not the headline metric"}
+    # the fork's complete fine-stage iteration (all ranks; last, it moves the parameters too): render() with the two
+    # extra deformation queries and the k = 100 kNN regularisers (gaussian_renderer/renderer.py:173-203), weighted as
+    # train.py:191-196, + grid regularisers (train.py:207-214) + AdamW
+    full_stage = None
+    if args.mode == "train" and not args.no_optimizer_pass:
+        def full_step():
+            image, _, _, _, _, rd, _ = R.render(cam, pc, deform, bg, shs_grad_hook=hook, regularise=True)
+            regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
+            knn_terms = (0.000001 * rd["momentum"] + rd["knn_xyz"] + 0.1 * rd["knn_long"] + rd["knn_rot"]
+                         + 0.001 * rd["shs"] + 0.001 * rd["scales"])
+            if not dp:
+                (F.l1_loss(image, target) + regul + knn_terms).backward()
+            else:
+                # the data-phase hook must not run here: positions / planes receive more gradient from the two extra
+                # queries after the centre query's backward, so only the SH hook stays early
+                ((F.l1_loss(image, target) + knn_terms) / world).backward()
+                bucket.all_reduce()
+                regul.backward()
+            opt.step()
+            for p in all_params:
+                p.grad = None
+
+        saved_hook = deform.deformation_net.data_grad_hook
+        deform.deformation_net.data_grad_hook = None
+        hook_saved, hook = hook, None          # the deformed SHs of the centre query are not the only SH gradient path here
+        for _ in range(max(2, args.warmup // 2)):
+            full_step()
+        sync()
+        t0 = time.perf_counter()
+        nfull = max(3, args.steps // 3)
+        for _ in range(nfull):
+            full_step()
+        sync()
+        dtf = time.perf_counter() - t0
+        hook = hook_saved
+        deform.deformation_net.data_grad_hook = saved_hook
+        if dp:
+            t = torch.tensor([dtf], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtf = float(t.item())
+        full_stage = {"value": round(world * nfull / dtf, 3), "unit": "view-iterations/s (3 deformation queries + kNN regularisers + fwd+bwd + grid regularisers + AdamW)",
+                      "ms_per_step": round(dtf / nfull * 1e3, 4), "steps": nfull,
+                      "note": "the fork's whole fine-stage iteration per view (gaussian_renderer/renderer.py:173-203, train.py:191-220,328); not the headline metric"}
     if rank == 0:
         out["with_optimizer"] = with_opt
+        out["full_fine_stage"] = full_stage
         if rehearse:
             out["rehearsal"] = "multi-rank code path in a process group of one rank: not a result"
         print(json.dumps(out), file=result_out, flush=True)

@@ -115,3 +115,40 @@ def test_recurrent_regulation_and_small_clouds():
         assert abs(float(got[key]) - float(want[key])) <= 1e-5 * abs(float(want[key])) + 1e-9, key
     for a, b in zip(dev, cpu):
         assert float((a.grad.cpu() - b.grad).abs().max()) <= 2e-5 * float(b.grad.abs().max()) + 1e-12
+
+
+def test_render_with_regularisers_matches_three_separate_queries():
+    """render(..., regularise=True): the reference's fine-stage 7-tuple.  The batched 2P-point query must give the
+    same dictionary as the reference's formulation (two more forward_dynamic calls at t -+ 1/(MAX_FRAME-1), scales
+    through exp, rotations of the centre query normalised and the other two raw, renderer.py:145-146,175-182) on the
+    oracle's expressions, and every term must reach the deformation parameters."""
+    from test_gpu_deformation import make_args
+    from oracle import deformation_ref as R
+    RD, syn = pkg("renderer"), pkg("synthetic")
+    torch.manual_seed(11)
+    dev = torch.device("cuda")
+    deform = pkg("scene.deformation").deform_network(make_args(R.DeformConfig(plane_channels=16, resolution=[16, 16, 16, 8], multires=[1, 2]))).to(dev)
+    _, cam_np, raw = syn.make_workload("C1", P=1500)
+    pc = RD.GaussianParams(raw, dev)
+    cam = RD.Camera(syn.look_at_camera(96, 64), dev, time=0.5)
+    out = RD.render(cam, pc, deform, torch.ones(3, device=dev), regularise=True)
+    assert len(out) == 7 and out[6] is None
+    reg = out[5]
+    n = 1500
+    full = lambda v: torch.full((n, 1), v, device=dev)
+    q = lambda t: deform.forward_dynamic(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features, full(t), full(0.0), None)
+    dt = 1.0 / (RD.MAX_FRAME - 1)
+    (m, s, r, _, h), (mp, sp, rp, _, hp), (mn, sn, rn, _, hn) = q(0.5), q(0.5 - dt), q(0.5 + dt)
+    c = lambda v: v.detach().cpu()
+    idx, dist = RR.knn_bruteforce(c(m), 100)
+    want = RR.temporal_regulation(c(pc._xyz), c(m), c(mp), c(mn), c(torch.exp(s)), c(torch.exp(sp)), c(torch.exp(sn)), c(h), c(hp), c(hn),
+                                  c(torch.nn.functional.normalize(r)), c(rp), c(rn), idx, dist)
+    for key in want:
+        assert abs(float(reg[key]) - float(want[key])) <= 2e-5 * abs(float(want[key])) + 1e-9, key
+    (out[0].mean() + sum(reg.values())).backward()
+    assert pc._xyz.grad is not None and torch.isfinite(pc._xyz.grad).all()
+    planes = [p for level in deform.deformation_net.grid.grids for p in level]
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in planes)
+    # the coarse stage has no regulariser terms (renderer.py:152-153)
+    coarse = RD.render(cam, pc, deform, torch.ones(3, device=dev), stage="coarse", regularise=True)
+    assert coarse[5] == {}
