@@ -819,6 +819,19 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 
     auto compute_group = [&](int t, const float4 (&src)[GEMM_GB]) {
         const int rb = wg + (t / NG) * nwg, g = t % NG;
+        // MASK: the epilogue's 32 mask values per lane are requested BEFORE the row block's last group is multiplied,
+        // so their memory latency hides behind the MFMAs (with one wave per SIMD nothing else would cover it)
+        float m0[16], m1[16];
+        if (MASK && !FUSE && g == NG - 1) {
+            const int mrow0 = rb * ROWS_PER_WG + wave * 32 + 4 * khalf;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = min(mrow0 + (r & 3) + 8 * (r >> 2), P - 1);
+                const float* mrow = Mk + (size_t)row * ldm;
+                m0[r] = mrow[min(col, N - 1)];
+                m1[r] = mrow[min(col + 32, N - 1)];
+            }
+        }
 #pragma unroll
         for (int b = 0; b < GEMM_GB; b++) {
             const int m = g * GEMM_GB + b;
@@ -879,18 +892,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
         }
         if (g == NG - 1 && !FUSE) {
             // epilogue: accumulator register r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
-            // All mask loads are issued before the first store.
             const int row0 = rb * ROWS_PER_WG + wave * 32 + 4 * khalf;
-            float m0[16], m1[16];
-            if (MASK) {
-#pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int row = min(row0 + (r & 3) + 8 * (r >> 2), P - 1);
-                    const float* mrow = Mk + (size_t)row * ldm;
-                    m0[r] = mrow[min(col, N - 1)];
-                    m1[r] = mrow[min(col + 32, N - 1)];
-                }
-            }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = row0 + (r & 3) + 8 * (r >> 2);
