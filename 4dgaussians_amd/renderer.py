@@ -42,6 +42,18 @@ class Camera:
         self.full_proj_transform = torch.from_numpy(cam.projmatrix).to(device)
         self.camera_center = torch.from_numpy(cam.campos).to(device)
         self.time, self.force = float(time), float(force)
+        self._columns = {}
+
+    def time_force_columns(self, n: int, device):
+        """(n, 1) columns filled with this view's time and force: constant per camera, so built once per point count
+        instead of two fill kernels per step (the reference rebuilds them every call, renderer.py:131-135)."""
+        key = (n, str(device), self.time, self.force)
+        cols = self._columns.get(key)
+        if cols is None:
+            self._columns.clear()
+            cols = self._columns[key] = (torch.full((n, 1), self.time, dtype=torch.float32, device=device),
+                                         torch.full((n, 1), self.force, dtype=torch.float32, device=device))
+        return cols
 
 
 MAX_FRAME = 25                                   # scene/dataset_readers.py:30: the regulariser's time step is 1 / (MAX_FRAME - 1)
@@ -71,8 +83,11 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
     means3D, opacity, scales, rotations = pc._xyz, pc._opacity, pc._scaling, pc._rotation
     if "coarse" not in stage and deform is not None:
         n = means3D.shape[0]
-        time = torch.full((n, 1), cam.time, dtype=torch.float32, device=means3D.device)
-        force = torch.full((n, 1), cam.force, dtype=torch.float32, device=means3D.device)
+        if hasattr(cam, "time_force_columns"):
+            time, force = cam.time_force_columns(n, means3D.device)
+        else:
+            time = torch.full((n, 1), cam.time, dtype=torch.float32, device=means3D.device)
+            force = torch.full((n, 1), cam.force, dtype=torch.float32, device=means3D.device)
         means3D, scales, rotations, opacity, shs = deform.forward_dynamic(means3D, scales, rotations, opacity, shs,
                                                                           time, force, None)
         if shs_grad_hook is not None and shs.requires_grad:

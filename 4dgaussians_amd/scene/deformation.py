@@ -362,7 +362,8 @@ class Deformation(nn.Module):
         params, cfg = cache
         cfg["data_grad_hook"] = self.data_grad_hook
         out = _DeformFunction.apply(points, scales, rotations, shs, time, force, cfg, *params)
-        return out[0], out[1], out[2], opacity[:, :1], out[3]
+        # opacity passes through (no_do): the reference's opacity[:, :1] is the tensor itself when it is (P, 1)
+        return out[0], out[1], out[2], opacity if opacity.shape[1] == 1 else opacity[:, :1], out[3]
 
     def get_mlp_parameters(self):
         return [p for n, p in self.named_parameters() if "grid" not in n]
