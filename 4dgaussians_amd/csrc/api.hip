@@ -9,6 +9,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <stdlib.h>
 #include "gs4d_internal.h"
 
 int gs4d_launch_scan(int P, GeomState& g, int debug, hipStream_t s);
@@ -145,10 +146,31 @@ size_t BinningState::required(size_t R)
     return (size_t)p + 256;
 }
 
+bool gs4d_sort_tile_first()
+{
+    static const bool v = [] { const char* e = getenv("GS4D_SORT"); return !(e && e[0] == 'l'); }();
+    return v;
+}
+
+uint32_t gs4d_sort_segment_cap()
+{
+    // GS4D_SORT_SEGMENT_CAP (tests): lists longer than this take the chunked global path; at most 2048 (SEG_CAP of binning.hip)
+    static const uint32_t v = [] {
+        const char* e = getenv("GS4D_SORT_SEGMENT_CAP");
+        long c = e ? atol(e) : 2048;
+        return (uint32_t)(c < 0 ? 0 : (c > 2048 ? 2048 : c));
+    }();
+    return v;
+}
+
+// Number of ping-pong writes the sort performs: decides which half holds the sorted lists (BinningState::sorted =
+// (n - 1) & 1), for the forward that runs the sort and for the backward / state view that only re-derive the layout.
 static int sort_passes(int W, int H)
 {
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
-    return (int)((32 + gs4d_higher_msb((uint32_t)(gx * gy)) + 7) / 8);
+    const int tbits = (int)gs4d_higher_msb((uint32_t)(gx * gy));
+    if (gs4d_sort_tile_first()) return (tbits + 7) / 8 + 1;      // tile passes + the per-tile depth sort
+    return (32 + tbits + 7) / 8;
 }
 
 extern "C" {

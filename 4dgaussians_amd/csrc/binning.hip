@@ -277,6 +277,202 @@ __global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_scatter_kernel(
     }
 }
 
+// ------------------------------------------------------------------ tile-first sort: per-tile depth sort in LDS
+// The LSD sort above moves every key through HBM six times (4 depth + 2 tile digits at C1-C4).  Tile-first order does
+// the same job with three trips: (1) the two stable passes on the TILE bits group the keys by tile, keeping emission
+// order (= ascending Gaussian index) inside a tile; (2) tile_bounds_kernel finds each tile's [begin, end); (3) one
+// workgroup per tile sorts its list by the 32 depth bits -- four stable 8-bit passes, ranked exactly like
+// sort_scatter_kernel (per-wave contiguous ownership, wave match-ballot, per-wave digit counters) -- with the list held
+// in LDS between passes, and writes it out once.  Stable on both levels, hence the same permutation as
+// the LSD sort, bit for bit.  Lists longer than SEG_CAP (rare: > 2048 Gaussians on one 16x16 tile) take the same
+// passes chunk by chunk through the two global buffers (slow, correct).
+#define SEG_CAP 2048
+
+__global__ __launch_bounds__(256) void tile_bounds_kernel(uint32_t R, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+{
+    const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R) return;
+    const uint32_t tile = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0)
+        ranges[tile].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (tile != prev) {
+            ranges[prev].y = idx;
+            ranges[tile].x = idx;
+        }
+    }
+    if (idx == R - 1) ranges[tile].y = R;
+}
+
+// The list lives in LDS between passes (two key / value buffers + the ranks); loops over rounds are dynamic, so the
+// kernel needs few registers and occupancy is set by its 46 KB of LDS (3 workgroups per CU).
+struct SegShared {
+    uint32_t cnt[4][256];        // per-wave digit counts -> exclusive offsets of the wave inside the chunk's digit run
+    uint32_t digit_start[256];   // first slot of each digit inside the chunk (fast path) / running global base (long lists)
+    uint32_t chunk_total[256];
+    uint32_t wave[4];
+    uint32_t k[2][SEG_CAP];
+    uint32_t v[2][SEG_CAP];
+    uint16_t rank[SEG_CAP];
+};
+
+// Ranks the n items of key[] (item (wave, round, lane) = position wave * 64 * rounds + round * 64 + lane):
+// on return S.rank[pos] = number of earlier items of the SAME WAVE with the same digit, S.cnt[w][d] = exclusive offset
+// of wave w among the chunk's items with digit d, S.chunk_total[d] = their number, and, if scan_digits,
+// S.digit_start[d] = exclusive scan of chunk_total.
+__device__ __forceinline__ void seg_rank_chunk(SegShared& S, const uint32_t* key, int rounds, int n, int shift, bool scan_digits)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    for (int i = tid; i < 4 * 256; i += 256) (&S.cnt[0][0])[i] = 0;
+    __syncthreads();
+    for (int r = 0; r < rounds; r++) {
+        const int pos = wave * 64 * rounds + r * 64 + lane;
+        const bool valid = pos < n;
+        const uint32_t d = valid ? (key[pos] >> shift) & 255u : 0u;
+        uint64_t same = __ballot(valid) ^ (valid ? 0ull : ~0ull);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint64_t m = __ballot((d >> b) & 1u);
+            same &= ((d >> b) & 1u) ? m : ~m;
+        }
+        const uint32_t before = (uint32_t)__popcll(same & lanemask_lt);
+        const int leader = __ffsll((unsigned long long)same) - 1;
+        uint32_t prev = 0;
+        if (valid && lane == leader) {
+            prev = S.cnt[wave][d];
+            S.cnt[wave][d] = prev + (uint32_t)__popcll(same);
+        }
+        prev = __shfl(prev, leader, 64);
+        if (valid) S.rank[pos] = (uint16_t)(prev + before);
+    }
+    __syncthreads();
+    {
+        const uint32_t c0 = S.cnt[0][tid], c1 = S.cnt[1][tid], c2 = S.cnt[2][tid], c3 = S.cnt[3][tid];
+        S.cnt[0][tid] = 0; S.cnt[1][tid] = c0; S.cnt[2][tid] = c0 + c1; S.cnt[3][tid] = c0 + c1 + c2;
+        const uint32_t total = c0 + c1 + c2 + c3;
+        S.chunk_total[tid] = total;
+        if (scan_digits) {
+            uint32_t incl = total;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) S.wave[wave] = incl;
+            __syncthreads();
+            uint32_t wp = 0;
+            for (int w = 0; w < wave; w++) wp += S.wave[w];
+            S.digit_start[tid] = wp + incl - total;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void segment_depth_sort_kernel(const uint2* __restrict__ ranges,
+                                                                 uint64_t* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
+                                                                 uint64_t* __restrict__ keys_b, uint32_t* __restrict__ vals_b,
+                                                                 uint32_t cap)
+{
+    __shared__ SegShared S;
+    const uint32_t tile = blockIdx.x;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    if (n <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t hi = (uint64_t)tile << 32;
+
+    if ((uint32_t)n <= cap) {
+        // ---- the list fits: input a -> LDS, four passes between the two LDS buffers, output b
+        const int rounds = (n + 255) >> 8;
+        for (int i = tid; i < n; i += 256) {
+            S.k[0][i] = (uint32_t)keys_a[range.x + i];
+            S.v[0][i] = vals_a[range.x + i];
+        }
+        __syncthreads();
+        for (int pass = 0; pass < 4; pass++) {
+            const int shift = 8 * pass, in = pass & 1, out = in ^ 1;
+            seg_rank_chunk(S, S.k[in], rounds, n, shift, true);
+            for (int r = 0; r < rounds; r++) {
+                const int pos = wave * 64 * rounds + r * 64 + lane;
+                if (pos < n) {
+                    const uint32_t kk = S.k[in][pos];
+                    const uint32_t d = (kk >> shift) & 255u;
+                    const uint32_t slot = S.digit_start[d] + S.cnt[wave][d] + S.rank[pos];
+                    S.k[out][slot] = kk;
+                    S.v[out][slot] = S.v[in][pos];
+                }
+            }
+            __syncthreads();
+        }
+        for (int i = tid; i < n; i += 256) {             // four passes: the result is back in buffer 0
+            keys_b[range.x + i] = hi | (uint64_t)S.k[0][i];
+            vals_b[range.x + i] = S.v[0][i];
+        }
+        return;
+    }
+
+    // ---- long list: the same four passes, chunk by chunk, ping-pong between the two global buffers
+    // (a -> b -> a -> b -> a), then a copy a -> b so that the result lands where the fast path puts it
+    for (int pass = 0; pass < 4; pass++) {
+        const int shift = 8 * pass;
+        const uint64_t* kin = ((pass & 1) ? keys_b : keys_a) + range.x;
+        const uint32_t* vin = ((pass & 1) ? vals_b : vals_a) + range.x;
+        uint64_t* kout = ((pass & 1) ? keys_a : keys_b) + range.x;
+        uint32_t* vout = ((pass & 1) ? vals_a : vals_b) + range.x;
+        // digit totals of the whole list -> running base of every digit
+        S.chunk_total[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += 256) atomicAdd(&S.chunk_total[((uint32_t)kin[i] >> shift) & 255u], 1u);
+        __syncthreads();
+        {
+            const uint32_t total = S.chunk_total[tid];
+            uint32_t incl = total;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) S.wave[wave] = incl;
+            __syncthreads();
+            uint32_t wp = 0;
+            for (int w = 0; w < wave; w++) wp += S.wave[w];
+            S.digit_start[tid] = wp + incl - total;
+        }
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += SEG_CAP) {
+            const int cn = min(SEG_CAP, n - c0);
+            const int rounds = (cn + 255) >> 8;
+            for (int i = tid; i < cn; i += 256) {
+                S.k[0][i] = (uint32_t)kin[c0 + i];
+                S.v[0][i] = vin[c0 + i];
+            }
+            __syncthreads();
+            seg_rank_chunk(S, S.k[0], rounds, cn, shift, false);
+            for (int r = 0; r < rounds; r++) {
+                const int pos = wave * 64 * rounds + r * 64 + lane;
+                if (pos < cn) {
+                    const uint32_t kk = S.k[0][pos];
+                    const uint32_t d = (kk >> shift) & 255u;
+                    const uint32_t dst = S.digit_start[d] + S.cnt[wave][d] + S.rank[pos];
+                    kout[dst] = hi | (uint64_t)kk;
+                    vout[dst] = S.v[0][pos];
+                }
+            }
+            __syncthreads();
+            S.digit_start[tid] += S.chunk_total[tid];
+            __syncthreads();
+        }
+        __threadfence();                                 // this workgroup re-reads what it wrote in the next pass
+        __syncthreads();
+    }
+    for (int i = tid; i < n; i += 256) {
+        keys_b[range.x + i] = keys_a[range.x + i];
+        vals_b[range.x + i] = vals_a[range.x + i];
+    }
+}
+
 // ------------------------------------------------------------------ tile ranges + inverse permutation
 // ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand); inv[emission slot] = sorted
 // position, recovered from the key's tile id and the Gaussian's rectangle (no extra sort payload).
@@ -313,10 +509,10 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, int gx, in
 
 }  // namespace
 
-// Stable LSD radix sort of (u64 key, u32 value) pairs on the low 8*passes key bits.  The input
+// Stable LSD radix sort of (u64 key, u32 value) pairs on key bits [first_shift, first_shift + 8*passes).  The input
 // arrays are left intact; the result lands in keys_tmp[*where] / vals_tmp[*where].
 // hist must hold 256 * gs4d_sort_blocks(R) + 256 words.
-int gs4d_radix_sort_pairs(uint32_t R, int passes, const uint64_t* keys_in, const uint32_t* vals_in,
+int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
                           uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
                           int debug, hipStream_t s)
 {
@@ -328,9 +524,9 @@ int gs4d_radix_sort_pairs(uint32_t R, int passes, const uint64_t* keys_in, const
     for (int p = 0; p < passes; p++) {
         uint64_t* kout = keys_tmp[p & 1];
         uint32_t* vout = vals_tmp[p & 1];
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, 8 * p, kin, hist, ntiles);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, first_shift + 8 * p, kin, hist, ntiles);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(256), 0, s, ntiles, hist, digit_totals);
-        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, 8 * p, kin, vin, kout,
+        hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, first_shift + 8 * p, kin, vin, kout,
                            vout, hist, digit_totals, ntiles);
         GS4D_LAUNCH_CHECK("radix_sort_pass", debug, s);
         kin = kout;
@@ -365,17 +561,29 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     GS4D_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
     if (R <= 0) return GS4D_OK;
 
-    const uint32_t bits = 32 + gs4d_higher_msb((uint32_t)(gx * gy));
-    const int passes = (int)((bits + 7) / 8);
+    const uint32_t tbits = gs4d_higher_msb((uint32_t)(gx * gy));
     int where = 0;
     int rc;
-    {
-    GS4D_PROF("radix_sort", s);
-    rc = gs4d_radix_sort_pairs((uint32_t)R, passes, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
+    if (gs4d_sort_tile_first()) {
+        GS4D_PROF("radix_sort", s);
+        const int tpasses = (int)((tbits + 7) / 8);
+        rc = gs4d_radix_sort_pairs((uint32_t)R, tpasses, 32, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
                                    b.hist, &where, debug, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(tile_bounds_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R,
+                           b.keys_tmp[where], im.ranges);
+        hipLaunchKernelGGL(segment_depth_sort_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.keys_tmp[where],
+                           b.values_tmp[where], b.keys_tmp[where ^ 1], b.values_tmp[where ^ 1], gs4d_sort_segment_cap());
+        GS4D_LAUNCH_CHECK("segment_depth_sort", debug, s);
+        where ^= 1;
+    } else {
+        GS4D_PROF("radix_sort", s);
+        const int passes = (int)((32 + tbits + 7) / 8);
+        rc = gs4d_radix_sort_pairs((uint32_t)R, passes, 0, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
+                                   b.hist, &where, debug, s);
+        if (rc) return rc;
     }
-    if (rc) return rc;
-    b.sorted = where;
+    if (where != b.sorted) { gs4d_set_error("binning: sorted lists ended in buffer %d, layout expects %d", where, b.sorted); return GS4D_EINVAL; }
     GS4D_PROF("tile_ranges", s);
     hipLaunchKernelGGL(tile_ranges_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
                        b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, im.ranges, b.inv);

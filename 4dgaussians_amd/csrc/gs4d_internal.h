@@ -106,7 +106,11 @@ static inline uint32_t gs4d_higher_msb(uint32_t n)
     return b == 0 ? 1 : b;
 }
 
-int gs4d_radix_sort_pairs(uint32_t R, int passes, const uint64_t* keys_in, const uint32_t* vals_in,
+// sort strategy of the binning stage (process-wide, read once from the environment: GS4D_SORT=lsd selects the
+// six-pass LSD sort; default is tile-first, see binning.hip) and the longest per-tile list sorted inside LDS
+bool gs4d_sort_tile_first();
+uint32_t gs4d_sort_segment_cap();
+int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
                           uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
                           int debug, hipStream_t s);
 

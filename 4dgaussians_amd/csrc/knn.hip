@@ -407,7 +407,7 @@ extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, 
     hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, bbox, codes, ids);
     GS4D_LAUNCH_CHECK("knn_morton", 0, s);
     int where = 0;
-    int rc = gs4d_radix_sort_pairs((uint32_t)P, 4, codes, ids, ktmp, vtmp, hist, &where, 0, s);
+    int rc = gs4d_radix_sort_pairs((uint32_t)P, 4, 0, codes, ids, ktmp, vtmp, hist, &where, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(gather_box_kernel, dim3(nboxes), dim3(KNN_BOX), 0, s, P, points, vtmp[where], sorted, boxes);
     hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, nboxes, sorted, boxes, mean_dist2);
@@ -458,7 +458,7 @@ extern "C" int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const
     hipLaunchKernelGGL(morton_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, xyz, bbox, codes, ids);
     GS4D_LAUNCH_CHECK("knn_query_morton", 0, s);
     int where = 0;
-    int rc = gs4d_radix_sort_pairs((uint32_t)n, 4, codes, ids, ktmp, vtmp, hist, &where, 0, s);
+    int rc = gs4d_radix_sort_pairs((uint32_t)n, 4, 0, codes, ids, ktmp, vtmp, hist, &where, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(kq_gather_box_kernel, dim3(nboxes), dim3(KQ_BOX), 0, s, n, xyz, vtmp[where], sorted, boxes);
     hipLaunchKernelGGL(kq_super_box_kernel, dim3(nsuper), dim3(64), 0, s, nboxes, boxes, supers);

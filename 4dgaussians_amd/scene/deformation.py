@@ -158,7 +158,7 @@ class _DeformFunction(torch.autograd.Function):
         if shs_.data_ptr() % 16:
             shs_ = shs_.clone()
         plan = cfg.get("plan")
-        if plan is not None and plan.in_place and plan.matches(params):
+        if plan is not None and plan.in_place and len(params) == len(plan.ptrs):   # storage checked by forward_dynamic
             d = plan.desc
         else:
             plan = None
