@@ -197,36 +197,24 @@ def main():
     bucket = par.GradBucket(all_params, early=[pc._features, *data_params], comm=comm)
     dp_hooks = os.environ.get("GS4D_BENCH_DP_HOOKS", "all")       # experiments: "all" | "shs" | "none"
 
-    host_ms = {"shs_hook": 0.0, "data_hook": 0.0, "all_reduce": 0.0, "backward": 0.0, "forward": 0.0}   # debug only
-
     def shs_hook(g):
-        t = time.perf_counter()
         bucket.early_reduce(pc._features, g)
-        host_ms["shs_hook"] += time.perf_counter() - t
 
     def data_hook(d_xyz, d_scaling, d_rotation, plane_grads, g_ftw, g_ftb):
-        t = time.perf_counter()
         bucket.early_reduce_many(data_params, [d_xyz, d_scaling, d_rotation, *plane_grads, g_ftw, g_ftb])
-        host_ms["data_hook"] += time.perf_counter() - t
 
     hook = shs_hook if dp and dp_hooks in ("all", "shs") else None
     if dp and dp_hooks == "all":
         deform.deformation_net.data_grad_hook = data_hook
 
     def train_step():
-        ta = time.perf_counter()
         image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
         loss = F.l1_loss(image, target)
         if dp:
             loss = loss / world                           # SUM over ranks == mean over the global batch
-        tb = time.perf_counter()
         loss.backward()
-        tc = time.perf_counter()
         if dp:
             bucket.all_reduce()
-        host_ms["forward"] += tb - ta
-        host_ms["backward"] += tc - tb
-        host_ms["all_reduce"] += time.perf_counter() - tc
         for p in all_params:
             p.grad = None
 
@@ -258,15 +246,12 @@ def main():
     L.gs4d_profile_select(None if args.no_stage_events else dominant.encode())
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     t0 = time.perf_counter()
-    for k in host_ms:
-        host_ms[k] = 0.0
     for i in range(args.steps):
         step()
     t_issued = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
-    _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step; host ms per step in "
-         + ", ".join(f"{k} {v / args.steps * 1e3:.3f}" for k, v in host_ms.items()))
+    _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step")
     _dbg(f"timed region done: {dt / args.steps * 1e3:.3f} ms per step")
     L.gs4d_profile_enable(0)
     if dp:
