@@ -120,16 +120,25 @@ class RcclComm:
         self._lib, self._comm, self._busy = lib, comm, False
         self._stream_handle = ctypes.c_void_p(self.stream.cuda_stream)
 
-    def all_reduce_sum(self, t: torch.Tensor):
-        """In-place SUM over the ranks of a dense float32 device tensor, asynchronous on the side stream."""
+    def all_reduce_sum(self, t: torch.Tensor, inline: bool = False):
+        """In-place SUM over the ranks of a dense float32 device tensor: asynchronous on the side stream, or, with
+        inline=True, on the caller's current stream (no cross-stream events: right for a small exchange that nothing
+        can overlap with anyway; it must not be issued while side-stream work of this communicator is pending on
+        another rank in a different order, so callers issue it after wait())."""
         if t.dtype != torch.float32 or not t.is_contiguous() or t.device != self.device:
             raise ValueError("RcclComm.all_reduce_sum: dense float32 tensor on the communicator's device expected")
-        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        cur = torch.cuda.current_stream(self.device)
+        if inline:
+            handle = ctypes.c_void_p(cur.cuda_stream)
+        else:
+            self.stream.wait_stream(cur)
+            handle = self._stream_handle
         ptr = t.data_ptr()
-        rc = self._lib.ncclAllReduce(ptr, ptr, t.numel(), self.FLOAT32, self.SUM, self._comm, self._stream_handle)
+        rc = self._lib.ncclAllReduce(ptr, ptr, t.numel(), self.FLOAT32, self.SUM, self._comm, handle)
         if rc != 0:
             raise RuntimeError("ncclAllReduce failed: " + self._lib.ncclGetErrorString(rc).decode())
-        self._busy = True
+        if not inline:
+            self._busy = True
 
     def wait(self):
         """Everything issued through all_reduce_sum() is ordered before what the current stream does next."""
@@ -208,9 +217,17 @@ class GradBucket:
             return False
         return dist.get_world_size() > 1 or self.exchange_in_world_of_one
 
-    def _reduce(self, region: torch.Tensor):
+    INLINE_BYTES = 2 << 20         # end-of-step regions up to this size run on the compute stream (RcclComm only)
+
+    def _reduce(self, region: torch.Tensor, at_end: bool = False):
         if self.comm is not None:
-            self.comm.all_reduce_sum(region)
+            if at_end and region.numel() * 4 <= self.INLINE_BYTES:
+                # the small tail of the step: nothing is left to overlap with, so skip the side stream and its two
+                # cross-stream events; ordered after the early collectives by waiting for the side stream first
+                self.comm.wait()
+                self.comm.all_reduce_sum(region, inline=True)
+            else:
+                self.comm.all_reduce_sum(region)
             if not self._pending:
                 self._pending.append(self.comm)
         else:
@@ -278,12 +295,12 @@ class GradBucket:
         for i in range(len(live_grads)):
             if i in done:
                 if run_begin is not None:
-                    self._reduce(self.flat[run_begin:self._bounds[i][0]])
+                    self._reduce(self.flat[run_begin:self._bounds[i][0]], at_end=True)
                     run_begin = None
             elif run_begin is None:
                 run_begin = self._bounds[i][0]
         if run_begin is not None:
-            self._reduce(self.flat[run_begin:total])
+            self._reduce(self.flat[run_begin:total], at_end=True)
         if not async_op:
             self.finish()
             return None
