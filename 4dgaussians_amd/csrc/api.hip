@@ -338,8 +338,10 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
     if (!inst_grad) { gs4d_set_error("backward scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)inst_grad & 255) { gs4d_set_error("backward scratch must be 256-byte aligned"); return GS4D_EINVAL; }
 
+    int rc = gs4d_launch_inverse_permutation(R, width, height, radii, g, b, debug, s);
+    if (rc) return rc;
     const float* features = colors_precomp ? colors_precomp : g.rgb;
-    int rc = gs4d_launch_blend_backward(width, height, R, g, b, im, features, background, dL_dpix, dL_dpix_depth,
+    rc = gs4d_launch_blend_backward(width, height, R, g, b, im, features, background, dL_dpix, dL_dpix_depth,
                                         inst_grad, debug, s);
     if (rc) return rc;
     const float* cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;

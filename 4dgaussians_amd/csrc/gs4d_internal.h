@@ -123,6 +123,8 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
                         int debug, hipStream_t s);
+int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b, int debug,
+                                    hipStream_t s);
 int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
                               const float* features, const float* bg, float* out_color, float* out_depth, int debug,
                               hipStream_t s);
