@@ -61,7 +61,7 @@ MAX_FRAME = 25                                   # scene/dataset_readers.py:30: 
 
 def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
            scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False, shs_grad_hook=None,
-           regularise: bool = False, max_frame: int = MAX_FRAME):
+           regularise: bool = False, max_frame: int = MAX_FRAME, _image_only: bool = False):
     """-> (image, screenspace_points, visibility_filter, radii, depth), as the first five items of the
     reference's 7-tuple (renderer.py:221); with regularise=True the full 7-tuple (..., reg_dict, None): reg_dict holds
     the fine stage's momentum / scales / shs / knn_xyz / knn_long / knn_rot terms (:173-203; empty in the coarse
@@ -69,9 +69,11 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
     two calls in the reference -- and the k = min(100, P) nearest neighbours of the deformed positions.  shs_grad_hook(grad), if given, is called during the backward pass as soon
     as dL/d(deformed SH coefficients) exists, i.e. before the deformation backward runs (data-parallel training
     starts the all-reduce of the SH gradients there, parallel.GradBucket.early_reduce)."""
-    screenspace_points = torch.zeros_like(pc._xyz, requires_grad=torch.is_grad_enabled())
-    if screenspace_points.requires_grad:
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros_like(pc._xyz, requires_grad=True)
         screenspace_points.retain_grad()
+    else:                                   # never read without a backward pass: no fill kernel for it
+        screenspace_points = torch.empty_like(pc._xyz)
     settings = GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
@@ -112,6 +114,8 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
                                        rotations, r2[:n], r2[n:])
     image, radii, depth = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
                                      opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+    if _image_only:
+        return image
     if regularise:
         return image, screenspace_points, radii > 0, radii, depth, reg_dict, None
     return image, screenspace_points, radii > 0, radii, depth
@@ -119,7 +123,7 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
 
 @torch.no_grad()
 def render_for_image(cam: Camera, pc: GaussianParams, deform, bg_color, scaling_modifier=1.0, stage="fine"):
-    return render(cam, pc, deform, bg_color, scaling_modifier, stage)[0]
+    return render(cam, pc, deform, bg_color, scaling_modifier, stage, _image_only=True)   # no visibility mask kernel
 
 
 def render_set_fps(views, pc, deform, bg_color, stage="fine"):
