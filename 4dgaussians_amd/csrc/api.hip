@@ -12,7 +12,7 @@
 #include <stdlib.h>
 #include "gs4d_internal.h"
 
-int gs4d_launch_scan(int P, GeomState& g, int debug, hipStream_t s);
+int gs4d_launch_scan(int P, GeomState& g, uint32_t* mailbox, uint32_t seq, int debug, hipStream_t s);
 
 static thread_local char g_err[512] = "";
 
@@ -275,13 +275,49 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
                                     cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height,
                                     tan_fovx, tan_fovy, prefiltered, radii, g, debug, s);
     if (rc) return rc;
-    rc = gs4d_launch_scan(P, g, debug, s);
+    // The one host round trip of the forward (rasterizer_impl.cu:282): num_rendered sizes the binning chunk.  The scan
+    // kernel posts it into a pinned host mailbox and the host spins on the sequence word -- a few microseconds instead
+    // of a D2H copy plus a stream synchronisation -- and the binning chunk is requested BEFORE the wait with the previous
+    // call's size plus 1/8 (the allocator callback runs Python), again afterwards only if that guess was too small.
+    static thread_local uint32_t* mailbox = nullptr;
+    static thread_local uint32_t mailbox_seq = 0;
+    static thread_local size_t last_R = 0;
+    static const bool use_mailbox = getenv("GS4D_NO_MAILBOX") == nullptr;
+    if (use_mailbox && !mailbox) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable) == hipSuccess) {
+            mailbox = (uint32_t*)p;
+            mailbox[0] = mailbox[1] = mailbox[2] = 0;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    const uint32_t seq = ++mailbox_seq ? mailbox_seq : ++mailbox_seq;       // never 0
+    rc = gs4d_launch_scan(P, g, mailbox, seq, debug, s);
     if (rc) return rc;
 
-    // one host sync to size the binning chunk (rasterizer_impl.cu:282)
+    char* bchunk = nullptr;
+    size_t guess_R = 0;
+    if (last_R) {
+        guess_R = last_R + last_R / 8 + 4096;
+        bchunk = (char*)binning_alloc(binning_ctx, BinningState::required(guess_R));
+        if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
+    }
+
     uint32_t host_counters[2] = {0, 0};
-    GS4D_HIP_CHECK(hipMemcpyAsync(host_counters, g.counters, sizeof host_counters, hipMemcpyDeviceToHost, s));
-    GS4D_HIP_CHECK(hipStreamSynchronize(s));
+    bool posted = false;
+    if (mailbox) {
+        volatile uint32_t* mb = mailbox;
+        for (long spin = 0; spin < 400000000L; spin++) {                    // a few seconds at most, then the slow path
+            if (__atomic_load_n(&mb[2], __ATOMIC_ACQUIRE) == seq) { posted = true; break; }
+            __builtin_ia32_pause();
+        }
+        if (posted) { host_counters[0] = mb[0]; host_counters[1] = mb[1]; }
+    }
+    if (!posted) {
+        GS4D_HIP_CHECK(hipMemcpyAsync(host_counters, g.counters, sizeof host_counters, hipMemcpyDeviceToHost, s));
+        GS4D_HIP_CHECK(hipStreamSynchronize(s));
+    }
     if (host_counters[1]) {
         gs4d_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
         return GS4D_EPREFILTER;
@@ -293,8 +329,11 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     const int R = (int)host_counters[0];
     if (num_rendered) *num_rendered = R;
 
-    char* bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R));
-    if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
+    if (!bchunk || (size_t)R > guess_R) {
+        bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R));
+        if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
+    }
+    last_R = (size_t)R;
     BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
 
     rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);

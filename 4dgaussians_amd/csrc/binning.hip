@@ -17,9 +17,12 @@ namespace {
 // ------------------------------------------------------------------ block-sum scan (1 workgroup)
 // block_offsets = exclusive scan of block_sums; counters[0] = total.  n is ceil(P/256)
 // (391 at P = 100k, 19.5k at P = 5M), so one 1024-lane workgroup looping over chunks is enough.
+// mailbox (may be null): three words of pinned host memory; the kernel posts (total, prefilter flag) and then the
+// sequence number the host is spinning on -- the host learns num_rendered without a stream synchronisation.
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ block_sums,
                                                                uint32_t* __restrict__ block_offsets,
-                                                               uint32_t* __restrict__ counters)
+                                                               uint32_t* __restrict__ counters,
+                                                               uint32_t* __restrict__ mailbox, uint32_t seq)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
@@ -45,7 +48,15 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
         __syncthreads();
     }
-    if (threadIdx.x == 0) counters[0] = s_carry;
+    if (threadIdx.x == 0) {
+        counters[0] = s_carry;
+        if (mailbox) {
+            mailbox[0] = s_carry;
+            mailbox[1] = counters[1];                  // written by the preprocess kernel (earlier in the stream)
+            __threadfence_system();
+            __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ key emission
@@ -539,12 +550,12 @@ int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_
     return GS4D_OK;
 }
 
-int gs4d_launch_scan(int P, GeomState& g, int debug, hipStream_t s)
+int gs4d_launch_scan(int P, GeomState& g, uint32_t* mailbox, uint32_t seq, int debug, hipStream_t s)
 {
     GS4D_PROF("scan", s);
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.block_offsets,
-                       g.counters);
+                       g.counters, mailbox, seq);
     GS4D_LAUNCH_CHECK("scan_block_sums", debug, s);
     return GS4D_OK;
 }
