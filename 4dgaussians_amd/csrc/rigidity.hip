@@ -183,3 +183,207 @@ extern "C" int gs4d_neighbor_diff_norm_backward_gather(int n, int k, int dim, co
     GS4D_LAUNCH_CHECK("neighbor_diff_norm_backward_gather", 0, s);
     return GS4D_OK;
 }
+
+// ---------------------------------------------------------------- the three kNN terms of the temporal branch, fused
+// gaussian_renderer/renderer.py:189-203 in one forward kernel (+ a one-workgroup sum) and one backward kernel:
+//   S_xyz  = sum_pairs w * |vx_j - vx_i|                      knn_xyz  = S_xyz / k / n
+//   S_long = sum_pairs w * | |vl_j - vl_i| - |vx_j - vx_i| |  knn_long = S_long / k / n
+//   S_rot  = sum_pairs (|r1_j - r1_i| + |r2_j - r2_i|)        knn_rot  = (S_rot / (n k)) * S_w / k / n   (:203 as written)
+//   S_w    = sum_pairs w,   w = exp(-100 dist)   (dist comes from detached positions: no gradient through w)
+// Nothing per pair is stored: the backward recomputes the four differences per edge (x stays in L2) and gathers over
+// the outgoing and the incoming edges of a row (transposed graph), so it needs neither atomics nor (n, k) temporaries.
+namespace {
+
+#define RIGT_BLOCKS 2048
+
+// The four fields of a row are packed into ONE 64-byte record (vx 3, vl 3, r1 4, r2 4, 2 pad): a pair then costs one
+// cache line for its neighbour instead of four.
+__global__ __launch_bounds__(256) void rigidity_pack_kernel(int n, const float* __restrict__ vx, const float* __restrict__ vl,
+                                                            const float* __restrict__ r1, const float* __restrict__ r2,
+                                                            float4* __restrict__ packed)
+{
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float4 a = *reinterpret_cast<const float4*>(r1 + (size_t)p * 4), b = *reinterpret_cast<const float4*>(r2 + (size_t)p * 4);
+    packed[(size_t)p * 4 + 0] = make_float4(vx[(size_t)p * 3], vx[(size_t)p * 3 + 1], vx[(size_t)p * 3 + 2], vl[(size_t)p * 3]);
+    packed[(size_t)p * 4 + 1] = make_float4(vl[(size_t)p * 3 + 1], vl[(size_t)p * 3 + 2], 0.f, 0.f);
+    packed[(size_t)p * 4 + 2] = a;
+    packed[(size_t)p * 4 + 3] = b;
+}
+
+struct RigRow { float vx[3], vl[3], r1[4], r2[4]; };
+__device__ __forceinline__ RigRow rig_load(const float4* __restrict__ packed, size_t p)
+{
+    const float4 q0 = packed[p * 4], q1 = packed[p * 4 + 1], q2 = packed[p * 4 + 2], q3 = packed[p * 4 + 3];
+    RigRow r;
+    r.vx[0] = q0.x; r.vx[1] = q0.y; r.vx[2] = q0.z; r.vl[0] = q0.w; r.vl[1] = q1.x; r.vl[2] = q1.y;
+    r.r1[0] = q2.x; r.r1[1] = q2.y; r.r1[2] = q2.z; r.r1[3] = q2.w;
+    r.r2[0] = q3.x; r.r2[1] = q3.y; r.r2[2] = q3.z; r.r2[3] = q3.w;
+    return r;
+}
+template <int D>
+__device__ __forceinline__ float rig_diff(const float (&b)[D], const float (&a)[D], float (&d)[D])
+{
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < D; c++) { d[c] = b[c] - a[c]; s += d[c] * d[c]; }
+    return sqrtf(s);
+}
+
+__global__ __launch_bounds__(256) void rigidity_terms_forward_kernel(size_t pairs, int k, int n, const float4* __restrict__ packed,
+                                                                     const long long* __restrict__ idx,
+                                                                     const float* __restrict__ dist,
+                                                                     float* __restrict__ partial /* [RIGT_BLOCKS][4] */)
+{
+    __shared__ float s[4][4];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < pairs; t += (size_t)RIGT_BLOCKS * 256) {
+        const size_t i = t / (size_t)k;
+        long long j = idx[t];
+        if (j < 0 || j >= n) j = (long long)i;
+        const float w = expf(-100.f * dist[t]);
+        const RigRow a = rig_load(packed, i), b = rig_load(packed, (size_t)j);
+        float d3[3], d4[4];
+        const float dx = rig_diff<3>(b.vx, a.vx, d3);
+        const float dl = rig_diff<3>(b.vl, a.vl, d3);
+        const float d1 = rig_diff<4>(b.r1, a.r1, d4);
+        const float d2 = rig_diff<4>(b.r2, a.r2, d4);
+        acc[0] += w * dx;
+        acc[1] += w * fabsf(dl - dx);
+        acc[2] += d1 + d2;
+        acc[3] += w;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        float v = acc[q];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        partial[(size_t)blockIdx.x * 4 + threadIdx.x] = (s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]);
+}
+
+// one workgroup: out[q] = sum over the blocks of partial[.][q], fixed order, double accumulation
+__global__ __launch_bounds__(256) void rigidity_terms_sum_kernel(const float* __restrict__ partial, float* __restrict__ out)
+{
+    __shared__ double s[4][4];
+    double acc[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < RIGT_BLOCKS; b += 256)
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc[q] += (double)partial[(size_t)b * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double v = acc[q];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) out[threadIdx.x] = (float)((s[0][threadIdx.x] + s[1][threadIdx.x]) + (s[2][threadIdx.x] + s[3][threadIdx.x]));
+}
+
+// gradient of one edge (A -> B, A = the row whose neighbour list holds B) with respect to the fields AT `self`
+// (sign +1 if self is B, -1 if self is A): accumulates into g[14] = (vx 3, vl 3, r1 4, r2 4)
+__device__ __forceinline__ void rig_edge(const RigRow& A, const RigRow& B, float w, float cx, float cl, float cr, float sign,
+                                         float (&g)[14])
+{
+    float dxv[3], dlv[3], d1v[4], d2v[4];
+    const float dx = rig_diff<3>(B.vx, A.vx, dxv), dl = rig_diff<3>(B.vl, A.vl, dlv);
+    const float d1 = rig_diff<4>(B.r1, A.r1, d1v), d2 = rig_diff<4>(B.r2, A.r2, d2v);
+    const float sg = dl > dx ? 1.f : (dl < dx ? -1.f : 0.f);                 // d|u|/du
+    const float kx = dx > 0.f ? sign * w * (cx - cl * sg) / dx : 0.f;        // knn_xyz through dx, knn_long through -dx
+    const float kl = dl > 0.f ? sign * w * cl * sg / dl : 0.f;
+    const float k1 = d1 > 0.f ? sign * cr / d1 : 0.f;
+    const float k2 = d2 > 0.f ? sign * cr / d2 : 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; c++) { g[c] += kx * dxv[c]; g[3 + c] += kl * dlv[c]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) { g[6 + c] += k1 * d1v[c]; g[10 + c] += k2 * d2v[c]; }
+}
+
+// one wave per row p.  coef (device): cx = dL/dS_xyz, cl = dL/dS_long, cr = dL/dS_rot
+__global__ __launch_bounds__(256) void rigidity_terms_backward_kernel(int n, int k, const float4* __restrict__ packed,
+                                                                      const long long* __restrict__ idx,
+                                                                      const float* __restrict__ dist,
+                                                                      const int* __restrict__ order,
+                                                                      const int* __restrict__ row_start,
+                                                                      const float* __restrict__ coef,
+                                                                      float* __restrict__ g_vx, float* __restrict__ g_vl,
+                                                                      float* __restrict__ g_r1, float* __restrict__ g_r2)
+{
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const float cx = coef[0], cl = coef[1], cr = coef[2];
+    const RigRow self = rig_load(packed, (size_t)p);
+    float g[14];
+#pragma unroll
+    for (int c = 0; c < 14; c++) g[c] = 0.f;
+    for (int s = lane; s < k; s += 64) {                         // outgoing edges p -> m: self is the tail
+        const size_t t = (size_t)p * k + s;
+        const long long m = idx[t];
+        if (m < 0 || m >= n || m == p) continue;
+        rig_edge(self, rig_load(packed, (size_t)m), expf(-100.f * dist[t]), cx, cl, cr, -1.f, g);
+    }
+    const int e1 = row_start[p + 1];
+    for (int e = row_start[p] + lane; e < e1; e += 64) {         // incoming edges i -> p: self is the head
+        const int t = order[e];
+        const int i = t / k;
+        if (i == p) continue;
+        rig_edge(rig_load(packed, (size_t)i), self, expf(-100.f * dist[t]), cx, cl, cr, 1.f, g);
+    }
+#pragma unroll
+    for (int c = 0; c < 14; c++) {
+        float v = g[c];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        g[c] = v;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { g_vx[(size_t)p * 3 + c] = g[c]; g_vl[(size_t)p * 3 + c] = g[3 + c]; }
+        *reinterpret_cast<float4*>(g_r1 + (size_t)p * 4) = make_float4(g[6], g[7], g[8], g[9]);
+        *reinterpret_cast<float4*>(g_r2 + (size_t)p * 4) = make_float4(g[10], g[11], g[12], g[13]);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t gs4d_rigidity_terms_scratch_bytes(void) { return sizeof(float) * 4 * RIGT_BLOCKS; }
+
+extern "C" int gs4d_rigidity_terms_forward(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
+                                           const float* rot2, const long long* idx, const float* dist, float* packed,
+                                           float* scratch, float* sums4, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 1 || k < 1 || !vel_xyz || !vel_long || !rot1 || !rot2 || !idx || !dist || !packed || !scratch || !sums4 ||
+        ((uintptr_t)rot1 & 15) || ((uintptr_t)rot2 & 15) || ((uintptr_t)packed & 15)) {
+        gs4d_set_error("gs4d_rigidity_terms_forward: bad sizes, null or misaligned pointer");
+        return GS4D_EINVAL;
+    }
+    GS4D_PROF("rigidity_forward", s);
+    hipLaunchKernelGGL(rigidity_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, vel_xyz, vel_long, rot1, rot2,
+                       (float4*)packed);
+    hipLaunchKernelGGL(rigidity_terms_forward_kernel, dim3(RIGT_BLOCKS), dim3(256), 0, s, (size_t)n * k, k, n,
+                       (const float4*)packed, idx, dist, scratch);
+    hipLaunchKernelGGL(rigidity_terms_sum_kernel, dim3(1), dim3(256), 0, s, scratch, sums4);
+    GS4D_LAUNCH_CHECK("rigidity_terms_forward", 0, s);
+    return GS4D_OK;
+}
+
+extern "C" int gs4d_rigidity_terms_backward(int n, int k, const float* packed, const long long* idx, const float* dist,
+                                            const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
+                                            float* g_vel_long, float* g_rot1, float* g_rot2, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 1 || k < 1 || (size_t)n * k > 0x7fffffffull || !packed || !idx || !dist || !order || !row_start || !coef3 ||
+        !g_vel_xyz || !g_vel_long || !g_rot1 || !g_rot2 || ((uintptr_t)packed & 15) || ((uintptr_t)g_rot1 & 15) ||
+        ((uintptr_t)g_rot2 & 15)) {
+        gs4d_set_error("gs4d_rigidity_terms_backward: bad sizes, null or misaligned pointer");
+        return GS4D_EINVAL;
+    }
+    GS4D_PROF("rigidity_backward", s);
+    hipLaunchKernelGGL(rigidity_terms_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, k, (const float4*)packed,
+                       idx, dist, order, row_start, coef3, g_vel_xyz, g_vel_long, g_rot1, g_rot2);
+    GS4D_LAUNCH_CHECK("rigidity_terms_backward", 0, s);
+    return GS4D_OK;
+}

@@ -85,6 +85,57 @@ def neighbor_diff_norm(x: torch.Tensor, idx: torch.Tensor, graph_t=None) -> torc
     return _NeighborDiffNorm.apply(x, idx, graph_t).view(idx.shape)
 
 
+class _RigidityTerms(torch.autograd.Function):
+    """(vel_xyz, vel_long, rot_v1, rot_v2, idx, dist, graph_t) -> tensor [3] = (knn_xyz, knn_long, knn_rot) of
+    renderer.py:194-203, one kernel forward, one backward (csrc/rigidity.hip); dist carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, vel_xyz, vel_long, rot_v1, rot_v2, idx, dist, graph_t):
+        dev = vel_xyz.device
+        n, k = vel_xyz.shape[0], idx.shape[-1]
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        vx, vl, r1, r2 = f(vel_xyz), f(vel_long), f(rot_v1), f(rot_v2)
+        if r1.data_ptr() % 16:
+            r1 = r1.clone()
+        if r2.data_ptr() % 16:
+            r2 = r2.clone()
+        idx_ = idx.reshape(n, k).to(torch.int64).contiguous()
+        dist_ = f(dist).reshape(n, k)
+        L = _cabi.lib()
+        L.gs4d_rigidity_terms_scratch_bytes.restype = C.c_size_t
+        scratch = torch.empty(int(L.gs4d_rigidity_terms_scratch_bytes()) // 4, dtype=torch.float32, device=dev)
+        packed = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        sums = torch.empty(4, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = L.gs4d_rigidity_terms_forward(C.c_int(n), C.c_int(k), _cabi.ptr(vx), _cabi.ptr(vl), _cabi.ptr(r1), _cabi.ptr(r2),
+                                               _cabi.ptr(idx_), _cabi.ptr(dist_), _cabi.ptr(packed), _cabi.ptr(scratch),
+                                               _cabi.ptr(sums), _cabi.current_stream(dev))
+        _cabi.check(rc, "gs4d_rigidity_terms_forward")
+        ctx.save_for_backward(packed, idx_, dist_, sums)
+        ctx.graph_t = graph_t
+        kn = float(k) * float(n)
+        # knn_xyz = S_xyz / kn, knn_long = S_long / kn, knn_rot = (S_rot / kn) * S_w / kn
+        return torch.stack([sums[0] / kn, sums[1] / kn, sums[2] / kn * sums[3] / kn])
+
+    @staticmethod
+    def backward(ctx, g):
+        packed, idx_, dist_, sums = ctx.saved_tensors
+        order, row_start = ctx.graph_t
+        n, k = idx_.shape
+        dev = packed.device
+        kn = float(k) * float(n)
+        g = g.to(torch.float32)
+        coef = torch.stack([g[0] / kn, g[1] / kn, g[2] * sums[3] / kn / kn]).contiguous()     # stays on the device
+        g_vx, g_vl = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev)
+        g_r1, g_r2 = torch.empty((n, 4), device=dev), torch.empty((n, 4), device=dev)
+        with torch.cuda.device(dev):
+            rc = _cabi.lib().gs4d_rigidity_terms_backward(
+                C.c_int(n), C.c_int(k), _cabi.ptr(packed), _cabi.ptr(idx_), _cabi.ptr(dist_), _cabi.ptr(order), _cabi.ptr(row_start),
+                _cabi.ptr(coef), _cabi.ptr(g_vx), _cabi.ptr(g_vl), _cabi.ptr(g_r1), _cabi.ptr(g_r2), _cabi.current_stream(dev))
+        _cabi.check(rc, "gs4d_rigidity_terms_backward")
+        return g_vx, g_vl, g_r1, g_r2, None, None, None
+
+
 def _neighbours(means3D_final, k):
     n = means3D_final.shape[0]
     k = min(int(k), n)
@@ -94,10 +145,12 @@ def _neighbours(means3D_final, k):
 
 
 def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scales_final, scales_prev, scales_nxt,
-                        shs_final, shs_prev, shs_nxt, rotations_final, rotations_prev, rotations_next, k=100):
+                        shs_final, shs_prev, shs_nxt, rotations_final, rotations_prev, rotations_next, k=100, fused=True):
     """The non-recurrent branch, renderer.py:173-203.  *_final / *_prev / *_nxt: the deformation at t, t - dt, t + dt
     (scales activated as at :145,:181-182; rotations_final activated as at :146, rotations_prev / _next as the
-    deformation returns them, exactly as the reference mixes them); means3D: the undeformed positions."""
+    deformation returns them, exactly as the reference mixes them); means3D: the undeformed positions.
+    fused=True computes the three kNN terms with gs4d_rigidity_terms_* (one kernel per direction); fused=False composes
+    them from neighbor_diff_norm and torch expressions, line by line as the reference."""
     reg = {}
     momentum_all = torch.abs(means3D_nxt + means3D_prev - 2 * means3D_final)
     reg["momentum"] = momentum_all.mean()
@@ -105,13 +158,23 @@ def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scale
     reg["shs"] = torch.abs(shs_nxt + shs_prev - 2 * shs_final).mean()
     vel_xyz = (means3D_nxt - means3D_final) / 2
     vel_long = means3D_nxt - means3D
+    rot_v1 = rotations_final - rotations_prev
+    rot_v2 = rotations_next - rotations_final
+    if fused:
+        # the three kNN terms in one kernel per direction (no (n, k) tensors at all); :203 as written: the MEAN of the
+        # rotation term scales the sum of the weights
+        n = means3D_final.shape[0]
+        k = min(int(k), n)
+        p = means3D_final[None].contiguous().detach()
+        idx, dist = knn(p, p, k)
+        terms = _RigidityTerms.apply(vel_xyz, vel_long, rot_v1, rot_v2, idx, dist, transpose_graph(idx))
+        reg["knn_xyz"], reg["knn_long"], reg["knn_rot"] = terms[0], terms[1], terms[2]
+        return reg
     k, n, idx, weight, gt = _neighbours(means3D_final, k)
     mom_xyz_dist = neighbor_diff_norm(vel_xyz, idx, gt)
     mom_long_dist = neighbor_diff_norm(vel_long, idx, gt)
     reg["knn_xyz"] = (weight * mom_xyz_dist).sum() / k / n
     reg["knn_long"] = (weight * torch.abs(mom_long_dist - mom_xyz_dist)).sum() / k / n
-    rot_v1 = rotations_final - rotations_prev
-    rot_v2 = rotations_next - rotations_final
     mom_rot_dist1 = neighbor_diff_norm(rot_v1, idx, gt)
     mom_rot_dist2 = neighbor_diff_norm(rot_v2, idx, gt)
     # :203 as written: the MEAN of the rotation term scales the sum of the weights

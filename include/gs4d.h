@@ -354,6 +354,21 @@ int gs4d_neighbor_diff_norm_backward_gather(int n, int k, int dim, const float* 
                                             const float* g, const int* order, const int* row_start, float* coef_scratch,
                                             float* dx, void* stream);
 
+/* The three kNN terms of the fine stage's temporal branch (gaussian_renderer/renderer.py:189-203) fused: forward ->
+ * sums4 = (S_xyz, S_long, S_rot, S_w) with w = exp(-100 dist) (definitions in csrc/rigidity.hip; knn_xyz = S_xyz/k/n,
+ * knn_long = S_long/k/n, knn_rot = S_rot/(n k) * S_w/k/n); backward -> gradients of the four fields given coef3 =
+ * (dL/dS_xyz, dL/dS_long, dL/dS_rot) in DEVICE memory and the transposed neighbour graph (order, row_start as for
+ * gs4d_neighbor_diff_norm_backward_gather).  vel_* [n,3], rot* [n,4] (16-byte aligned), idx [n,k] int64, dist [n,k];
+ * scratch: gs4d_rigidity_terms_scratch_bytes().  The gradients are written (not accumulated), deterministic. */
+size_t gs4d_rigidity_terms_scratch_bytes(void);
+/* packed: [n][16] floats (16-byte aligned), filled by the forward (one 64-byte record per row) and read by the backward */
+int gs4d_rigidity_terms_forward(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
+                                const float* rot2, const long long* idx, const float* dist, float* packed, float* scratch,
+                                float* sums4, void* stream);
+int gs4d_rigidity_terms_backward(int n, int k, const float* packed, const long long* idx, const float* dist,
+                                 const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
+                                 float* g_vel_long, float* g_rot1, float* g_rot2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,16 +78,21 @@ def test_neighbor_diff_norm_edge_cases():
         rig.neighbor_diff_norm(torch.zeros(4, 3), torch.zeros(1, 4, 2, dtype=torch.int64))     # CPU tensors: no CPU path
 
 
-def test_temporal_regulation_matches_reference_expressions():
+@pytest.mark.parametrize("fused", [True, False], ids=["fused_terms", "composed"])
+def test_temporal_regulation_matches_reference_expressions(fused):
     rig = pkg("rigidity")
     n, k = 600, 100
     cpu = {a: v.clone().requires_grad_(True) for a, v in _scene(n, 7).items()}
     idx, dist = RR.knn_bruteforce(cpu["means3D_final"].detach(), k)
     want = RR.temporal_regulation(*[cpu[a] for a in NAMES], idx, dist)
-    sum(want.values()).backward()
     dev = {a: v.detach().clone().cuda().requires_grad_(True) for a, v in cpu.items()}
-    got = rig.temporal_regulation(*[dev[a] for a in NAMES], k=k)
-    sum(got.values()).backward()
+    got = rig.temporal_regulation(*[dev[a] for a in NAMES], k=k, fused=fused)
+    # distinct weights per term, so that a gradient routed to the wrong term cannot cancel out
+    wts = {"momentum": 0.7, "scales": 1.3, "shs": 0.9, "knn_xyz": 1.1, "knn_long": 0.6, "knn_rot": 1.7}
+    for q in cpu.values():
+        q.grad = None
+    sum(wts[key] * want[key] for key in want).backward()
+    sum(wts[key] * got[key] for key in got).backward()
     assert set(got) == set(want) == {"momentum", "scales", "shs", "knn_xyz", "knn_long", "knn_rot"}
     for key in want:
         assert abs(float(got[key]) - float(want[key])) <= 1e-5 * abs(float(want[key])) + 1e-9, key
