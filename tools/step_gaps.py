@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 step = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 thr = float(sys.argv[3]) if len(sys.argv) > 3 else 4.0
-idx = [i for i, r in enumerate(rows) if "hexplane_forward_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "hexplane_pe_forward_kernel" in r["Kernel_Name"] or "hexplane_forward_kernel" in r["Kernel_Name"]]
 a, b = idx[step], idx[step + 1]
 busy = sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[a:b])
 span = int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"])

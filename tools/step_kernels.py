@@ -4,7 +4,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 step = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 pat = sys.argv[3] if len(sys.argv) > 3 else "."
-idx = [i for i, r in enumerate(rows) if "hexplane_forward_kernel" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "hexplane_pe_forward_kernel" in r["Kernel_Name"] or "hexplane_forward_kernel" in r["Kernel_Name"]]
 for r in rows[idx[step]:idx[step + 1]]:
     n = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]); n = re.sub(r"^void ", "", n).split("(")[0]
     if re.search(pat, n):
