@@ -8,8 +8,8 @@
 //   RAST/cuda_rasterizer/backward.cu:20-139   SH backward
 //   RAST/cuda_rasterizer/backward.cu:278-341  cov3D -> scale / rotation (no normalisation Jacobian)
 // The two reference kernels are fused into one pass; Gaussians covering more than
-// GS4D_BIG_ROWS tiles are deferred to a second launch where a whole workgroup sums their rows
-// (fixed lane assignment + fixed-order LDS tree, so still deterministic) -- otherwise one lane
+// GS4D_BIG_ROWS tiles are deferred to a second launch where a whole wave sums their rows
+// (fixed lane assignment + fixed-order shuffle tree, so still deterministic) -- otherwise one lane
 // would walk thousands of dependent gathers.
 // Compiled with -ffp-contract=off like the forward preprocess.
 #include "gs4d_internal.h"
@@ -301,13 +301,14 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
     gaussian_backward(A, idx, r);
 }
 
-// One workgroup per deferred Gaussian: lane t sums rows first+t, first+t+256, ... then a
-// fixed-order LDS tree combines the 256 partials.
+// One WAVE per deferred Gaussian (four per workgroup, no workgroup barriers): lane t sums rows first+t, first+t+64, ...,
+// a fixed-order shuffle tree combines the 64 partials and lane 0 finishes the Gaussian.
 __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
 {
-    __shared__ float s_red[256][NQ + 1];
+    const int lane = threadIdx.x & 63;
     const uint32_t n_big = *A.big_count;
-    for (uint32_t w = blockIdx.x; w < n_big; w += gridDim.x) {
+    const uint32_t nwaves = gridDim.x * 4u;
+    for (uint32_t w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_big; w += nwaves) {      // wave-uniform
         const int idx = (int)A.big_list[w];
         const uint32_t cnt = A.tiles_touched[idx];
         const uint32_t end = A.point_offsets[idx];
@@ -316,29 +317,17 @@ __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
 #pragma unroll
         for (int q = 0; q < NQ; q++) r[q] = 0.f;
         const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
-        for (uint32_t s = first + threadIdx.x; s < end; s += 256) {
+        for (uint32_t s = first + lane; s < end; s += 64) {
             const uint32_t k = A.inv[s];
             const float4 a = rows[(size_t)k * 3 + 0], b = rows[(size_t)k * 3 + 1], c = rows[(size_t)k * 3 + 2];
             r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
             r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
             r[8] += c.x; r[9] += c.y;
         }
-        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < NQ; q++) s_red[threadIdx.x][q] = r[q];
-        __syncthreads();
-        for (int off = 128; off >= 1; off >>= 1) {
-            if ((int)threadIdx.x < off) {
-#pragma unroll
-                for (int q = 0; q < NQ; q++) s_red[threadIdx.x][q] += s_red[threadIdx.x + off][q];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-#pragma unroll
-            for (int q = 0; q < NQ; q++) r[q] = s_red[0][q];
-            gaussian_backward(A, idx, r);
-        }
+        for (int q = 0; q < NQ; q++)
+            for (int off = 32; off >= 1; off >>= 1) r[q] += __shfl_xor(r[q], off, 64);
+        if (lane == 0) gaussian_backward(A, idx, r);
     }
 }
 
