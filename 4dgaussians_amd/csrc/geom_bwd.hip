@@ -291,7 +291,24 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
 #pragma unroll
     for (int q = 0; q < NQ; q++) r[q] = 0.f;
     const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
-    for (uint32_t s = first; s < end; s++) {
+    // The kernel waits on memory ~90 % of the time and every step of this walk is a dependent pair of gathers
+    // (inv -> row): four steps are issued together (16 loads in flight), summed in the same order as one by one.
+    uint32_t s = first;
+    for (; s + 4 <= end; s += 4) {
+        uint32_t k[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) k[u] = A.inv[s + u];
+        float4 a[4], b[4], c[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { a[u] = rows[(size_t)k[u] * 3 + 0]; b[u] = rows[(size_t)k[u] * 3 + 1]; c[u] = rows[(size_t)k[u] * 3 + 2]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            r[0] += a[u].x; r[1] += a[u].y; r[2] += a[u].z; r[3] += a[u].w;
+            r[4] += b[u].x; r[5] += b[u].y; r[6] += b[u].z; r[7] += b[u].w;
+            r[8] += c[u].x; r[9] += c[u].y;
+        }
+    }
+    for (; s < end; s++) {
         const uint32_t k = A.inv[s];
         const float4 a = rows[(size_t)k * 3 + 0], b = rows[(size_t)k * 3 + 1], c = rows[(size_t)k * 3 + 2];
         r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
