@@ -267,6 +267,14 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
         for (int bit = 62; bit >= 0; bit--) {
             const u64 b = 1ull << bit;
             if (bit < 32 && bit >= idbits) { known |= b; continue; }
+            if (bit == idbits - 1) {
+                // the distance half is decided.  Unless several candidates TIE at the k-th distance and not all of
+                // them are needed, the index bits need no selection: every key with that distance is kept.
+                int ceq = 0;
+#pragma unroll
+                for (int s = 0; s < 4; s++) ceq += __popcll(__ballot(ok[s] && ((my[s] & known) == prefix)));
+                if (ceq == need) { prefix |= (1ull << idbits) - 1ull; break; }
+            }
             int c = 0;
 #pragma unroll
             for (int s = 0; s < 4; s++) c += __popcll(__ballot(ok[s] && ((my[s] & known) == prefix) && !(my[s] & b)));
