@@ -262,25 +262,49 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
         u64 my[4]; bool ok[4];
 #pragma unroll
         for (int s = 0; s < 4; s++) { const int i = lane + 64 * s; ok[s] = i < cnt; my[s] = ok[s] ? keys[i] : ~0ull; }
-        u64 prefix = 0ull, known = 0ull;
-        int need = kk;
-        for (int bit = 62; bit >= 0; bit--) {
-            const u64 b = 1ull << bit;
-            if (bit < 32 && bit >= idbits) { known |= b; continue; }
-            if (bit == idbits - 1) {
-                // the distance half is decided.  Unless several candidates TIE at the k-th distance and not all of
-                // them are needed, the index bits need no selection: every key with that distance is kept.
-                int ceq = 0;
+        // `alive[s]`: the slot still matches the prefix chosen so far.  Per bit and slot that leaves one bit test, one
+        // ballot and one popcount (the kernel is bound by the CU's scalar unit: ballots, popcounts and the uniform
+        // bookkeeping are all scalar instructions), and the two key halves are walked as 32-bit words.
+        bool alive[4];
+        uint32_t hi[4], lo[4];
 #pragma unroll
-                for (int s = 0; s < 4; s++) ceq += __popcll(__ballot(ok[s] && ((my[s] & known) == prefix)));
-                if (ceq == need) { prefix |= (1ull << idbits) - 1ull; break; }
-            }
+        for (int s = 0; s < 4; s++) { alive[s] = ok[s]; hi[s] = (uint32_t)(my[s] >> 32); lo[s] = (uint32_t)my[s]; }
+        uint32_t phi = 0u, plo = 0u;
+        int need = kk;
+        for (int bit = 30; bit >= 0; bit--) {                 // distance half (bit 31 = sign of d2 = 0)
+            const uint32_t m = 1u << bit;
+            bool z[4];
             int c = 0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) c += __popcll(__ballot(ok[s] && ((my[s] & known) == prefix) && !(my[s] & b)));
-            if (need > c) { need -= c; prefix |= b; }
-            known |= b;
+            for (int s = 0; s < 4; s++) { z[s] = alive[s] && !(hi[s] & m); c += __popcll(__ballot(z[s])); }
+            const bool one = need > c;                         // uniform
+            if (one) { need -= c; phi |= m; }
+#pragma unroll
+            for (int s = 0; s < 4; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
         }
+        {
+            // the distance half is decided.  Unless several candidates TIE at the k-th distance and not all of them
+            // are needed, the index bits need no selection: every key with that distance is kept.
+            int ceq = 0;
+#pragma unroll
+            for (int s = 0; s < 4; s++) ceq += __popcll(__ballot(alive[s]));
+            if (ceq == need) {
+                plo = idbits >= 32 ? 0xffffffffu : ((1u << idbits) - 1u);
+            } else {
+                for (int bit = idbits - 1; bit >= 0; bit--) {   // bits [idbits, 32) of the index half are always 0
+                    const uint32_t m = 1u << bit;
+                    bool z[4];
+                    int c = 0;
+#pragma unroll
+                    for (int s = 0; s < 4; s++) { z[s] = alive[s] && !(lo[s] & m); c += __popcll(__ballot(z[s])); }
+                    const bool one = need > c;
+                    if (one) { need -= c; plo |= m; }
+#pragma unroll
+                    for (int s = 0; s < 4; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
+                }
+            }
+        }
+        const u64 prefix = ((u64)phi << 32) | (u64)plo;
         const u64 kth = prefix;
         int base = 0;
 #pragma unroll
