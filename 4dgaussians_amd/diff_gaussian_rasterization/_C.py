@@ -38,8 +38,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     if device.type != "cuda":
         raise RuntimeError("rasterize_gaussians needs tensors on a HIP device; there is no CPU path")
     P, H, W = means3D.size(0), int(image_height), int(image_width)
+    # With P != 0 the forward writes every pixel (blend) and every radius (preprocess): no clearing fill.  With no
+    # points the library returns at once (rasterize_points.cu:82) and the zero-initialised outputs are the result.
     out_color, out_depth, radii = _cabi.zeros_group(device, (NUM_CHANNELS, H, W), (1, H, W), (P,),
-                                                    dtypes=(torch.float32, torch.float32, torch.int32))
+                                                    dtypes=(torch.float32, torch.float32, torch.int32), _fill=(P == 0))
     geom, binning, img = (_cabi.TensorAllocator(device) for _ in range(3))
     rendered = C.c_int(0)
     if P != 0:

@@ -65,8 +65,10 @@ int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
  *   P Gaussians, D active SH degree, M SH coefficients per Gaussian (0 if shs == NULL);
  *   exactly one of (shs, colors_precomp) and one of ((scales, rotations), cov3D_precomp)
  *   is non-NULL; viewmatrix / projmatrix are the 16-float transposed matrices of
- *   scene/cameras.py:103-105.  out_color [3,H,W], out_depth [1,H,W] and radii [P] must be
- *   zero-initialised by the caller (rasterize_points.cu:68-70).
+ *   scene/cameras.py:103-105.  out_color [3,H,W], out_depth [1,H,W] and radii [P] are
+ *   written in full when P != 0 (every pixel by the blend, every radius by the preprocess),
+ *   so the caller need not clear them; with P == 0 the call returns at once and leaves them
+ *   untouched (the reference's caller hands over zeros, rasterize_points.cu:68-70).
  * *num_rendered receives the number of (Gaussian, tile) instances.  One host
  * synchronisation on `stream` happens inside (to size the binning buffer), as in
  * rasterizer_impl.cu:282.
