@@ -35,6 +35,21 @@ def _call_with_snapshot(fn, args, debug, dump_name, note):
         raise
 
 
+_zeros_cache = {}
+
+
+def _shared_zeros(shape, device):
+    """A read-only zero tensor for an absent upstream gradient (the library only reads it), kept per shape and
+    device instead of being allocated and filled in every backward."""
+    key = (tuple(shape), device.type, device.index)
+    z = _zeros_cache.get(key)
+    if z is None:
+        if len(_zeros_cache) >= 8:
+            _zeros_cache.clear()
+        z = _zeros_cache[key] = torch.zeros(shape, dtype=torch.float32, device=device)
+    return z
+
+
 class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
@@ -48,6 +63,9 @@ class _RasterizeGaussians(torch.autograd.Function):
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered
+        # autograd would otherwise launch two fills per backward: zeros for the (unused) depth gradient and for
+        # the non-differentiable radii
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii)
@@ -59,9 +77,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer = \
             ctx.saved_tensors
         if grad_out_color is None:
-            grad_out_color = torch.zeros((3, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
+            grad_out_color = _shared_zeros((3, s.image_height, s.image_width), means3D.device)
         if grad_depth is None:
-            grad_depth = torch.zeros((1, s.image_height, s.image_width), dtype=torch.float32, device=means3D.device)
+            grad_depth = _shared_zeros((1, s.image_height, s.image_width), means3D.device)
         args = (s.bg, means3D, radii, colors_precomp, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                 s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, grad_out_color, grad_depth, sh, s.sh_degree,
                 s.campos, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, s.debug)

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _shared_zeros
 from .fused import activate
 
 
@@ -70,8 +70,9 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
     as dL/d(deformed SH coefficients) exists, i.e. before the deformation backward runs (data-parallel training
     starts the all-reduce of the SH gradients there, parallel.GradBucket.early_reduce)."""
     if torch.is_grad_enabled():
-        screenspace_points = torch.zeros_like(pc._xyz, requires_grad=True)
-        screenspace_points.retain_grad()
+        # a fresh leaf (its .grad is the screen-space gradient the densifier reads) over a shared, read-only block of
+        # zeros: the rasterizer never reads or writes the values, so no allocation + fill per view
+        screenspace_points = _shared_zeros(tuple(pc._xyz.shape), pc._xyz.device).detach().requires_grad_(True)
     else:                                   # never read without a backward pass: no fill kernel for it
         screenspace_points = torch.empty_like(pc._xyz)
     settings = GaussianRasterizationSettings(
