@@ -377,7 +377,7 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
     if (!inst_grad) { gs4d_set_error("backward scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)inst_grad & 255) { gs4d_set_error("backward scratch must be 256-byte aligned"); return GS4D_EINVAL; }
 
-    int rc = gs4d_launch_inverse_permutation(R, width, height, radii, g, b, debug, s);
+    int rc = gs4d_launch_inverse_permutation(R, width, height, radii, g, b, gs4d_backward_big_count(inst_grad, R), debug, s);
     if (rc) return rc;
     const float* features = colors_precomp ? colors_precomp : g.rgb;
     rc = gs4d_launch_blend_backward(width, height, R, g, b, im, features, background, dL_dpix, dL_dpix_depth,

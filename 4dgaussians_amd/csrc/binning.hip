@@ -15,7 +15,8 @@ using namespace gs4d;
 namespace {
 
 // ------------------------------------------------------------------ block-sum scan (1 workgroup)
-// block_offsets = exclusive scan of block_sums; counters[0] = total.  n is ceil(P/256)
+// block_offsets = exclusive scan of block_sums (bits 0..30; bit 31 is the workgroup's prefilter flag); counters[0] =
+// total, counters[1] = OR of the flags (both words are written here: nothing clears them).  n is ceil(P/256)
 // (391 at P = 100k, 19.5k at P = 5M), so one 1024-lane workgroup looping over chunks is enough.
 // mailbox (may be null): three words of pinned host memory; the kernel posts (total, prefilter flag) and then the
 // sequence number the host is spinning on -- the host learns num_rendered without a stream synchronisation.
@@ -29,9 +30,12 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
     __syncthreads();
+    int flag = 0;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
-        const uint32_t v = i < n ? block_sums[i] : 0u;
+        const uint32_t raw = i < n ? block_sums[i] : 0u;
+        const uint32_t v = raw & 0x7fffffffu;
+        flag |= (int)(raw >> 31);
         uint32_t incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -48,11 +52,13 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
         __syncthreads();
     }
+    const int any_flag = __syncthreads_or(flag);
     if (threadIdx.x == 0) {
         counters[0] = s_carry;
+        counters[1] = any_flag ? 1u : 0u;
         if (mailbox) {
             mailbox[0] = s_carry;
-            mailbox[1] = counters[1];                  // written by the preprocess kernel (earlier in the stream)
+            mailbox[1] = any_flag ? 1u : 0u;
             __threadfence_system();
             __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -69,8 +75,11 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
     int P, int gx, int gy, const float2* __restrict__ means2D, const float* __restrict__ depths,
     const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ point_offsets,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ values)
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint2* __restrict__ ranges, int ntiles)
 {
+    // the tile ranges start as (0, 0) (empty tile); this launch is the first of the binning stage and has lanes to spare
+    for (int t = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x; t < ntiles; t += gridDim.x * GS4D_PRE_BLOCK)
+        ranges[t] = make_uint2(0u, 0u);
     __shared__ uint32_t s_incl[GS4D_PRE_BLOCK];   // inclusive scan of counts inside the workgroup
     __shared__ uint32_t s_wave[GS4D_PRE_BLOCK / 64];
     __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
@@ -485,7 +494,7 @@ __global__ __launch_bounds__(256) void segment_depth_sort_kernel(const uint2* __
 }
 
 // ------------------------------------------------------------------ tile ranges + inverse permutation
-// ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand); inv[emission slot] = sorted
+// ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand by emit_keys_kernel); inv[emission slot] = sorted
 // position, recovered from the key's tile id and the Gaussian's rectangle (no extra sort payload).
 template <bool RANGES, bool INV>
 __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, int gx, int gy,
@@ -494,10 +503,12 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, int gx, in
                                                           const float2* __restrict__ means2D,
                                                           const int* __restrict__ radii,
                                                           const uint32_t* __restrict__ point_offsets,
-                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ inv)
+                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ inv,
+                                                          uint32_t* __restrict__ clear_word)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= R) return;
+    if (idx == 0 && clear_word) *clear_word = 0u;
     const uint32_t tile = (uint32_t)(keys_sorted[idx] >> 32);
     if (RANGES) {
         if (idx == 0)
@@ -568,11 +579,11 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     {
     GS4D_PROF("emit_keys", s);
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
-                       radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted);
+                       radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
+                       im.ranges, gx * gy);
     GS4D_LAUNCH_CHECK("emit_keys", debug, s);
     }
 
-    GS4D_HIP_CHECK(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)gx * gy, s));
     if (R <= 0) return GS4D_OK;
 
     const uint32_t tbits = gs4d_higher_msb((uint32_t)(gx * gy));
@@ -603,21 +614,23 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     if (!gs4d_sort_tile_first()) {
         GS4D_PROF("tile_ranges", s);
         hipLaunchKernelGGL((tile_ranges_kernel<true, false>), dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
-                           b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, im.ranges, b.inv);
+                           b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, im.ranges, b.inv,
+                           (uint32_t*)nullptr);
         GS4D_LAUNCH_CHECK("tile_ranges", debug, s);
     }
     return GS4D_OK;
 }
 
 // inv[emission slot] = sorted position, for the per-Gaussian gather of the backward pass
-int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b, int debug,
-                                    hipStream_t s)
+int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b,
+                                    uint32_t* clear_word, int debug, hipStream_t s)
 {
     if (R <= 0) return GS4D_OK;
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     GS4D_PROF("inverse_permutation", s);
     hipLaunchKernelGGL((tile_ranges_kernel<false, true>), dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
-                       b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, (uint2*)nullptr, b.inv);
+                       b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, (uint2*)nullptr, b.inv,
+                       clear_word);
     GS4D_LAUNCH_CHECK("inverse_permutation", debug, s);
     return GS4D_OK;
 }

@@ -373,10 +373,9 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
     A.dL_ddepth = dL_ddepth; A.dL_dmean3D = dL_dmean3D; A.dL_dcov3D = dL_dcov3D; A.dL_dsh = dL_dsh;
     A.dL_dscale = dL_dscale; A.dL_drot = dL_drot;
     // deferred-Gaussian worklist lives behind the per-instance rows (see gs4d_backward_scratch_bytes)
-    char* tail = (char*)inst_grad + gs4d_align_up((size_t)R * GS4D_GRAD_ROW * sizeof(float), 256);
-    A.big_count = (uint32_t*)tail;
-    A.big_list = (uint32_t*)(tail + 256);
-    GS4D_HIP_CHECK(hipMemsetAsync(A.big_count, 0, 256, s));
+    // the counter was cleared by the inverse-permutation kernel at the start of the backward (api.hip)
+    A.big_count = gs4d_backward_big_count(inst_grad, R);
+    A.big_list = (uint32_t*)((char*)A.big_count + 256);
     hipLaunchKernelGGL(geom_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, A);
     GS4D_LAUNCH_CHECK("geom_backward", debug, s);
     hipLaunchKernelGGL(geom_backward_big_kernel, dim3(1024), dim3(256), 0, s, A);

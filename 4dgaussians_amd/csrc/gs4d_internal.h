@@ -123,8 +123,15 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
                         int debug, hipStream_t s);
-int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b, int debug,
-                                    hipStream_t s);
+// clear_word (may be null): one device word the kernel also sets to zero -- the backward's deferred-Gaussian counter,
+// which would otherwise cost a memset node of its own in front of the per-Gaussian kernel
+int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b,
+                                    uint32_t* clear_word, int debug, hipStream_t s);
+// the deferred-Gaussian counter of the backward scratch (layout: gs4d_backward_scratch_bytes)
+static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
+{
+    return (uint32_t*)((char*)inst_grad + gs4d_align_up((size_t)R * GS4D_GRAD_ROW * sizeof(float), 256));
+}
 int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
                               const float* features, const float* bg, float* out_color, float* out_depth, int debug,
                               hipStream_t s);

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int gx, int gy, int prefiltered,
     int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds,
     float* __restrict__ rgb, float4* __restrict__ conic_opacity, uint8_t* __restrict__ clamped,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ counters)
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums)
 {
     __shared__ float s_view[16], s_proj[16], s_cam[3];
     __shared__ uint32_t s_wave_sum[GS4D_PRE_BLOCK / 64];
@@ -69,6 +69,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     const int idx = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
     int my_radius_i = 0;
+    int bad = 0;
     if (idx < P) {
         const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
         const float3 p_view = affine_point(p_orig, s_view);
@@ -129,23 +130,24 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
                 }
             }
         } else if (prefiltered) {
-            counters[1] = 1u;  // reference traps here (auxiliary.h:156-160); we flag and report GS4D_EPREFILTER
+            bad = 1;  // reference traps here (auxiliary.h:156-160); we flag and report GS4D_EPREFILTER
         }
         radii[idx] = my_radius_i;
         tiles_touched[idx] = my_tiles;
     }
 
-    // workgroup sum of tile counts -> block_sums[blockIdx.x]
+    // workgroup sum of tile counts -> block_sums[blockIdx.x]; bit 31 carries the workgroup's prefilter flag to the scan
+    // kernel (a sum stays below 2^31: 256 Gaussians x tiles of the image), so no counter has to be cleared beforehand
     uint32_t v = my_tiles;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_down(v, off, 64);
     if ((threadIdx.x & 63) == 0) s_wave_sum[threadIdx.x >> 6] = v;
-    __syncthreads();
+    const int any_bad = __syncthreads_or(bad);
     if (threadIdx.x == 0) {
         uint32_t t = 0;
 #pragma unroll
         for (int w = 0; w < GS4D_PRE_BLOCK / 64; w++) t += s_wave_sum[w];
-        block_sums[blockIdx.x] = t;
+        block_sums[blockIdx.x] = (t & 0x7fffffffu) | (any_bad ? 0x80000000u : 0u);
     }
 }
 
@@ -173,12 +175,11 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
-    GS4D_HIP_CHECK(hipMemsetAsync(g.counters, 0, 64 * sizeof(uint32_t), s));
     hipLaunchKernelGGL(preprocess_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                        projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, prefiltered, radii,
                        g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.clamped, g.tiles_touched,
-                       g.block_sums, g.counters);
+                       g.block_sums);
     GS4D_LAUNCH_CHECK("preprocess", debug, s);
     return GS4D_OK;
 }
