@@ -650,9 +650,12 @@ __global__ __launch_bounds__(256) void pe_backward_kernel(PeArgs a, const float*
                                                           const float* __restrict__ scales,
                                                           const float* __restrict__ rots, const float* __restrict__ dZ,
                                                           float* __restrict__ dxyz, float* __restrict__ dscales,
-                                                          float* __restrict__ drots)
+                                                          float* __restrict__ drots, int* __restrict__ clear, int nclear)
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    // the cell histograms of the plane backward (next launch in the stream) start at zero: cleared here, by lanes this
+    // launch has to spare, instead of by a memset node of its own
+    for (size_t i = gid; i < (size_t)nclear; i += (size_t)gridDim.x * 256) clear[i] = 0;
     const size_t p = gid / 10;
     if (p >= (size_t)a.P) return;
     const int comp = (int)(gid % 10);
@@ -1659,7 +1662,8 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
     if (do_data) {
         const size_t threads = (size_t)P * 10;
         hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pa, points,
-                           scales, rotations, dZ, dL_dpoints, dL_dscales_in, dL_drotations_in);
+                           scales, rotations, dZ, dL_dpoints, dL_dscales_in, dL_drotations_in, hist,
+                           d->L * HEX_SORTS * hex_bins(d).nbins);
         GS4D_LAUNCH_CHECK("pe_backward", 0, s);
     }
     delete mlp_scope;
@@ -1675,7 +1679,6 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         int lanes_shift = 0;
         while ((1 << lanes_shift) < (d->C < 64 ? d->C : 64)) lanes_shift++;
         const HexBins B = hex_bins(d);
-        GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, sizeof(int) * d->L * HEX_SORTS * B.nbins, s));
         int lpp_shift = 0;
         while ((1 << lpp_shift) < d->C / 4) lpp_shift++;
         const size_t threads = (size_t)P << lpp_shift;
