@@ -295,7 +295,7 @@ def main():
         def pmc_traffic(kernel_prefix):
             """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
             try:
-                d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_v10.json")))
+                d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_v11.json")))
                 for k, v in d["kernels"].items():
                     if k.startswith(kernel_prefix) and args.config == "C2" and args.P is None:
                         return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
@@ -311,7 +311,7 @@ def main():
             achieved = alg_bytes / sec / 1e9
             roofline = {"kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("blend_backward_kernel"),
-                        "traffic_note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_traffic_v10.json (separate rocprofv3 --pmc passes)",
+                        "traffic_note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_traffic_v11.json (separate rocprofv3 --pmc passes)",
                         "avg_launch_ms": round(stages["blend_backward"], 4), "algorithmic_bytes": alg_bytes,
                         "note": "kernel is fp32-VALU/LDS bound, not HBM bound: see valu_* fields",
                         "valu_pairs": pairs_bwd, "valu_flop_per_pair": 60,
