@@ -255,3 +255,36 @@ def test_prefiltered_violation_is_reported():
     with pytest.raises(RuntimeError, match="prefiltered"):
         rast(means3D=dev(a["means3D"]), means2D=dev(a["means3D"]), opacities=dev(a["opacities"]), shs=dev(a["sh"]),
              scales=dev(a["scales"]), rotations=dev(a["rotations"]))
+
+
+def _dirty_allocator():
+    """Leave NaN bit patterns in the blocks torch's caching allocator hands out next: outputs and scratch tables
+    that are no longer cleared by a fill (colour / depth / radii, tile ranges, counters) must not depend on them."""
+    junk = [torch.full((n,), float("nan"), device="cuda") for n in (64, 1 << 10, 1 << 14, 1 << 18, 1 << 20, 1 << 22, 1 << 24)
+            for _ in range(3)]
+    torch.cuda.synchronize()
+    del junk
+
+
+def test_outputs_do_not_depend_on_previous_buffer_contents():
+    # a few small Gaussians on a large image: most tiles are empty (ranges (0, 0)), most pixels are background
+    a, cam = scene(40, 320, 240, 11, 0.02)
+    _dirty_allocator()
+    check_forward(a, cam, 3, bg=(0.2, 0.4, 0.6))
+    # every Gaussian behind the camera: nothing is rendered, the image is the background, depth and radii are zero
+    b = {k: v.copy() for k, v in a.items()}
+    b["means3D"] = (np.asarray(cam.campos, np.float32)[None, :] * 1.5 +
+                    np.random.default_rng(5).normal(0, 0.05, (40, 3))).astype(np.float32)
+    _dirty_allocator()
+    R, color, depth, radii, *_ = run_c(b, cam, 3, bg=(0.2, 0.4, 0.6))
+    assert R == 0
+    assert int(radii.abs().max()) == 0 and float(depth.abs().max()) == 0.0
+    want = torch.tensor((0.2, 0.4, 0.6), device="cuda").view(3, 1, 1).expand_as(color)
+    assert torch.equal(color, want)
+    # a prefilter violation (flag carried in the block sums, no cleared counter) leaves no state behind
+    rast = dgr().GaussianRasterizer(settings(cam, 3, prefiltered=True))
+    with pytest.raises(RuntimeError, match="prefiltered"):
+        rast(means3D=dev(b["means3D"]), means2D=dev(b["means3D"]), opacities=dev(b["opacities"]), shs=dev(b["sh"]),
+             scales=dev(b["scales"]), rotations=dev(b["rotations"]))
+    _dirty_allocator()
+    check_forward(a, cam, 3)
