@@ -186,7 +186,16 @@ __global__ __launch_bounds__(256) void mean_dist_kernel(int P, int nboxes, const
 // one point per lane, appended through a ballot-prefix compaction.  Queries are processed in Morton order so
 // neighbouring waves touch the same boxes.  Exact: bit-identical distances, identical indices up to that tie.
 #define KQ_BOX 64
+// Buffer size and cut-back trigger, measured at 100 k points (k = 100): 256 / 192 -> 1.12 ms; 192 / 128 1.38, 256 / 160 1.43,
+// 256 / 128 1.68, 384 / 320 1.36, 512 / 448 1.67 ms: cutting back earlier costs more selects than the tighter bound saves,
+// cutting back later scans more boxes with a loose bound.
+#ifndef KQ_CAP
 #define KQ_CAP 256
+#endif
+#define KQ_SLOTS (KQ_CAP / 64)
+#ifndef KQ_TRIGGER
+#define KQ_TRIGGER (KQ_CAP - KQ_BOX)     // candidates in the buffer beyond which it is cut back to the k best
+#endif
 #define KQ_MAXK 128
 typedef unsigned long long u64;
 
@@ -259,48 +268,48 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
     // Bit 63 (sign of d2) is always 0 and bits [idbits, 32) of the index half are always 0.
     auto shrink = [&](int kk) {
         __builtin_amdgcn_wave_barrier();
-        u64 my[4]; bool ok[4];
+        u64 my[KQ_SLOTS]; bool ok[KQ_SLOTS];
 #pragma unroll
-        for (int s = 0; s < 4; s++) { const int i = lane + 64 * s; ok[s] = i < cnt; my[s] = ok[s] ? keys[i] : ~0ull; }
+        for (int s = 0; s < KQ_SLOTS; s++) { const int i = lane + 64 * s; ok[s] = i < cnt; my[s] = ok[s] ? keys[i] : ~0ull; }
         // `alive[s]`: the slot still matches the prefix chosen so far.  Per bit and slot that leaves one bit test, one
         // ballot and one popcount (the kernel is bound by the CU's scalar unit: ballots, popcounts and the uniform
         // bookkeeping are all scalar instructions), and the two key halves are walked as 32-bit words.
-        bool alive[4];
-        uint32_t hi[4], lo[4];
+        bool alive[KQ_SLOTS];
+        uint32_t hi[KQ_SLOTS], lo[KQ_SLOTS];
 #pragma unroll
-        for (int s = 0; s < 4; s++) { alive[s] = ok[s]; hi[s] = (uint32_t)(my[s] >> 32); lo[s] = (uint32_t)my[s]; }
+        for (int s = 0; s < KQ_SLOTS; s++) { alive[s] = ok[s]; hi[s] = (uint32_t)(my[s] >> 32); lo[s] = (uint32_t)my[s]; }
         uint32_t phi = 0u, plo = 0u;
         int need = kk;
         for (int bit = 30; bit >= 0; bit--) {                 // distance half (bit 31 = sign of d2 = 0)
             const uint32_t m = 1u << bit;
-            bool z[4];
+            bool z[KQ_SLOTS];
             int c = 0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) { z[s] = alive[s] && !(hi[s] & m); c += __popcll(__ballot(z[s])); }
+            for (int s = 0; s < KQ_SLOTS; s++) { z[s] = alive[s] && !(hi[s] & m); c += __popcll(__ballot(z[s])); }
             const bool one = need > c;                         // uniform
             if (one) { need -= c; phi |= m; }
 #pragma unroll
-            for (int s = 0; s < 4; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
+            for (int s = 0; s < KQ_SLOTS; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
         }
         {
             // the distance half is decided.  Unless several candidates TIE at the k-th distance and not all of them
             // are needed, the index bits need no selection: every key with that distance is kept.
             int ceq = 0;
 #pragma unroll
-            for (int s = 0; s < 4; s++) ceq += __popcll(__ballot(alive[s]));
+            for (int s = 0; s < KQ_SLOTS; s++) ceq += __popcll(__ballot(alive[s]));
             if (ceq == need) {
                 plo = idbits >= 32 ? 0xffffffffu : ((1u << idbits) - 1u);
             } else {
                 for (int bit = idbits - 1; bit >= 0; bit--) {   // bits [idbits, 32) of the index half are always 0
                     const uint32_t m = 1u << bit;
-                    bool z[4];
+                    bool z[KQ_SLOTS];
                     int c = 0;
 #pragma unroll
-                    for (int s = 0; s < 4; s++) { z[s] = alive[s] && !(lo[s] & m); c += __popcll(__ballot(z[s])); }
+                    for (int s = 0; s < KQ_SLOTS; s++) { z[s] = alive[s] && !(lo[s] & m); c += __popcll(__ballot(z[s])); }
                     const bool one = need > c;
                     if (one) { need -= c; plo |= m; }
 #pragma unroll
-                    for (int s = 0; s < 4; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
+                    for (int s = 0; s < KQ_SLOTS; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
                 }
             }
         }
@@ -308,7 +317,7 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
         const u64 kth = prefix;
         int base = 0;
 #pragma unroll
-        for (int s = 0; s < 4; s++) {
+        for (int s = 0; s < KQ_SLOTS; s++) {
             const bool keep = ok[s] && my[s] <= kth;
             const u64 mask = __ballot(keep);
             if (keep) keys[base + __popcll(mask & lt)] = my[s];
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
         const u64 mask = __ballot(keep);
         if (keep) keys[cnt + __popcll(mask & lt)] = key;
         cnt += __popcll(mask);
-        if (cnt > KQ_CAP - KQ_BOX && cnt > k) shrink(k);
+        if (cnt > KQ_TRIGGER && cnt > k) shrink(k);
     };
 
     // seed: the boxes around the query's own place in the Morton order (or around the closest box)
