@@ -193,6 +193,9 @@ __global__ __launch_bounds__(256) void mean_dist_kernel(int P, int nboxes, const
 #define KQ_CAP 256
 #endif
 #define KQ_SLOTS (KQ_CAP / 64)
+#ifndef KQ_COARSE
+#define KQ_COARSE 15                         // low distance bits a coarse cut-back does not select on
+#endif
 #ifndef KQ_TRIGGER
 #define KQ_TRIGGER (KQ_CAP - KQ_BOX)     // candidates in the buffer beyond which it is cut back to the k best
 #endif
@@ -266,7 +269,10 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
 
     // k-th smallest (1-based kk <= cnt) of the cnt keys: radix select over ballots, most significant bit first.
     // Bit 63 (sign of d2) is always 0 and bits [idbits, 32) of the index half are always 0.
-    auto shrink = [&](int kk) {
+    // exact = false: only the upper distance bits are selected and the bound is rounded UP (low bits set), which keeps
+    // every key up to that bound -- at least kk, a few more when candidates share the upper bits.  Enough to tighten
+    // the acceptance bound during the scan at two thirds of the cost; the last call is exact.
+    auto shrink = [&](int kk, bool exact) {
         __builtin_amdgcn_wave_barrier();
         u64 my[KQ_SLOTS]; bool ok[KQ_SLOTS];
 #pragma unroll
@@ -280,7 +286,8 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
         for (int s = 0; s < KQ_SLOTS; s++) { alive[s] = ok[s]; hi[s] = (uint32_t)(my[s] >> 32); lo[s] = (uint32_t)my[s]; }
         uint32_t phi = 0u, plo = 0u;
         int need = kk;
-        for (int bit = 30; bit >= 0; bit--) {                 // distance half (bit 31 = sign of d2 = 0)
+        const int last = exact ? 0 : KQ_COARSE;
+        for (int bit = 30; bit >= last; bit--) {              // distance half (bit 31 = sign of d2 = 0)
             const uint32_t m = 1u << bit;
             bool z[KQ_SLOTS];
             int c = 0;
@@ -291,7 +298,10 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
 #pragma unroll
             for (int s = 0; s < KQ_SLOTS; s++) alive[s] = one ? (alive[s] && !z[s]) : z[s];
         }
-        {
+        if (!exact) {
+            phi |= (1u << KQ_COARSE) - 1u;
+            plo = 0xffffffffu;
+        } else {
             // the distance half is decided.  Unless several candidates TIE at the k-th distance and not all of them
             // are needed, the index bits need no selection: every key with that distance is kept.
             int ceq = 0;
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
             if (keep) keys[base + __popcll(mask & lt)] = my[s];
             base += __popcll(mask);
         }
-        cnt = base;                // == kk: keys are unique
+        cnt = base;                // exact: == kk (keys are unique); coarse: >= kk
         tau = kth + 1ull;
         tau_d2 = __uint_as_float((uint32_t)(kth >> 32));
         __builtin_amdgcn_wave_barrier();
@@ -338,7 +348,10 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
         const u64 mask = __ballot(keep);
         if (keep) keys[cnt + __popcll(mask & lt)] = key;
         cnt += __popcll(mask);
-        if (cnt > KQ_TRIGGER && cnt > k) shrink(k);
+        if (cnt > KQ_TRIGGER && cnt > k) {
+            shrink(k, false);
+            if (cnt > KQ_TRIGGER) shrink(k, true);          // many candidates inside one coarse bucket (duplicates)
+        }
     };
 
     // seed: the boxes around the query's own place in the Morton order (or around the closest box)
@@ -362,7 +375,7 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
     int s0 = max(0, b0 - nseed / 2), s1 = min(nboxes, s0 + nseed);
     s0 = max(0, s1 - nseed);
     for (int b = s0; b < s1; b++) scan_box(b);
-    if (cnt > k) shrink(k);
+    if (cnt > k) shrink(k, false);
 
     // every other box whose AABB can still hold a better candidate
     for (int sb0 = 0; sb0 < nsuper; sb0 += 64) {
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
             }
         }
     }
-    if (cnt > k) shrink(k);
+    if (cnt > k) shrink(k, true);
     __builtin_amdgcn_wave_barrier();
 
     // ascending order by counting ranks (keys are unique); unfilled slots keep (1e10, 0) as in the reference
