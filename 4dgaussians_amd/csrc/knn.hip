@@ -50,10 +50,23 @@ __global__ __launch_bounds__(256) void bbox_partial_kernel(int P, const float* _
 
 __global__ __launch_bounds__(64) void bbox_final_kernel(int n, const float* __restrict__ partial, float* __restrict__ bbox)
 {
-    if (threadIdx.x < 6) {
-        float v = 0.f;
-        for (int i = 0; i < n; i++) v = threadIdx.x < 3 ? fminf(v, partial[i * 6 + threadIdx.x]) : fmaxf(v, partial[i * 6 + threadIdx.x]);
-        bbox[threadIdx.x] = v;
+    // one wave: lane l folds the partial boxes l, l + 64, ..., then a shuffle tree (min / max: the order does not matter)
+    float mn[3] = {0.f, 0.f, 0.f}, mx[3] = {0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < n; i += 64)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            mn[a] = fminf(mn[a], partial[i * 6 + a]);
+            mx[a] = fmaxf(mx[a], partial[i * 6 + 3 + a]);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        for (int off = 32; off >= 1; off >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) { bbox[a] = mn[a]; bbox[3 + a] = mx[a]; }
     }
 }
 
