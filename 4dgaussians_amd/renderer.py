@@ -56,6 +56,7 @@ class Camera:
         return cols
 
 
+BATCHED_QUERY_MAX_POINTS = 2_000_000             # above this the regularised render queries the field three times instead of once
 MAX_FRAME = 25                                   # scene/dataset_readers.py:30: the regulariser's time step is 1 / (MAX_FRAME - 1)
 
 
@@ -91,8 +92,27 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
         else:
             time = torch.full((n, 1), cam.time, dtype=torch.float32, device=means3D.device)
             force = torch.full((n, 1), cam.force, dtype=torch.float32, device=means3D.device)
-        means3D, scales, rotations, opacity, shs = deform.forward_dynamic(means3D, scales, rotations, opacity, shs,
-                                                                          time, force, None)
+        extra = None
+        if regularise:
+            # the regularisers need the field at t - dt and t + dt too (reference: two more calls, :173-180): ONE query of
+            # 3 P points -- every parameter gradient of the field is then produced once instead of being summed over
+            # calls by autograd (one add kernel per parameter and call), and the launches are a third as many
+            dt = 1.0 / (max_frame - 1)
+            if n <= BATCHED_QUERY_MAX_POINTS:
+                three = lambda t: torch.cat([t, t, t], dim=0)
+                times = torch.cat([time, time - dt, time + dt], dim=0)
+                out3 = deform.forward_dynamic(three(means3D), three(scales), three(rotations), three(opacity), three(shs),
+                                              times, three(force), None)
+                parts = [o.view(3, n, *o.shape[1:]).unbind(0) for o in out3]
+            else:                           # the field's scratch grows with the rows of a call: three calls, as the reference
+                calls = [deform.forward_dynamic(means3D, scales, rotations, opacity, shs, t_, force, None)
+                         for t_ in (time, time - dt, time + dt)]
+                parts = list(zip(*calls))
+            means3D, scales, rotations, opacity, shs = (q[0] for q in parts)
+            extra = parts
+        else:
+            means3D, scales, rotations, opacity, shs = deform.forward_dynamic(means3D, scales, rotations, opacity, shs,
+                                                                              time, force, None)
         if shs_grad_hook is not None and shs.requires_grad:
             shs.register_hook(shs_grad_hook)
     raw_inputs = (pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features if hasattr(pc, "_features") else None)
@@ -100,19 +120,10 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
     reg_dict = {}
     if regularise and "coarse" not in stage and deform is not None:
         from .rigidity import temporal_regulation
-        n = pc._xyz.shape[0]
-        dt = 1.0 / (max_frame - 1)
-        xyz0, sc0, rot0, op0, shs0 = raw_inputs
-        if shs0 is None:
-            shs0 = pc.get_features
-        two = lambda t: torch.cat([t, t], dim=0)
-        times = torch.cat([torch.full((n, 1), cam.time - dt, dtype=torch.float32, device=xyz0.device),
-                           torch.full((n, 1), cam.time + dt, dtype=torch.float32, device=xyz0.device)], dim=0)
-        forces = torch.full((2 * n, 1), cam.force, dtype=torch.float32, device=xyz0.device)
-        m2, s2, r2, _, h2 = deform.forward_dynamic(two(xyz0), two(sc0), two(rot0), two(op0), two(shs0), times, forces, None)
-        s2 = torch.exp(s2)                                               # pc.scaling_activation, renderer.py:181-182
-        reg_dict = temporal_regulation(xyz0, means3D, m2[:n], m2[n:], scales, s2[:n], s2[n:], shs, h2[:n], h2[n:],
-                                       rotations, r2[:n], r2[n:])
+        xyz0 = raw_inputs[0]
+        m3, s3, r3, _, h3 = extra
+        reg_dict = temporal_regulation(xyz0, means3D, m3[1], m3[2], scales, torch.exp(s3[1]), torch.exp(s3[2]), shs, h3[1], h3[2],
+                                       rotations, r3[1], r3[2])            # torch.exp: pc.scaling_activation, renderer.py:181-182
     image, radii, depth = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, colors_precomp=None,
                                      opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
     if _image_only:

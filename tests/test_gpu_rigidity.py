@@ -123,7 +123,7 @@ def test_recurrent_regulation_and_small_clouds():
 
 
 def test_render_with_regularisers_matches_three_separate_queries():
-    """render(..., regularise=True): the reference's fine-stage 7-tuple.  The batched 2P-point query must give the
+    """render(..., regularise=True): the reference's fine-stage 7-tuple.  The batched 3P-point query must give the
     same dictionary as the reference's formulation (two more forward_dynamic calls at t -+ 1/(MAX_FRAME-1), scales
     through exp, rotations of the centre query normalised and the other two raw, renderer.py:145-146,175-182) on the
     oracle's expressions, and every term must reach the deformation parameters."""
@@ -154,6 +154,24 @@ def test_render_with_regularisers_matches_three_separate_queries():
     assert pc._xyz.grad is not None and torch.isfinite(pc._xyz.grad).all()
     planes = [p for level in deform.deformation_net.grid.grids for p in level]
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in planes)
+    # very large scenes query the field three times instead of once (BATCHED_QUERY_MAX_POINTS): same image, same
+    # dictionary, same gradients (plane gradients are float-atomic sums: 1e-5 of their magnitude)
+    batched_grads = {"xyz": pc._xyz.grad.clone(), "planes": [p.grad.clone() for p in planes]}
+    for p in list(pc.parameters()) + list(deform.parameters()):
+        p.grad = None
+    saved = RD.BATCHED_QUERY_MAX_POINTS
+    RD.BATCHED_QUERY_MAX_POINTS = 0
+    try:
+        out2 = RD.render(cam, pc, deform, torch.ones(3, device=dev), regularise=True)
+    finally:
+        RD.BATCHED_QUERY_MAX_POINTS = saved
+    assert torch.equal(out2[0], out[0])
+    for key in reg:
+        assert abs(float(out2[5][key]) - float(reg[key])) <= 1e-6 * abs(float(reg[key])) + 1e-12, key
+    (out2[0].mean() + sum(out2[5].values())).backward()
+    tol = lambda a, b: float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+    assert tol(pc._xyz.grad, batched_grads["xyz"])
+    assert all(tol(p.grad, g) for p, g in zip(planes, batched_grads["planes"]))
     # the coarse stage has no regulariser terms (renderer.py:152-153)
     coarse = RD.render(cam, pc, deform, torch.ones(3, device=dev), stage="coarse", regularise=True)
     assert coarse[5] == {}
