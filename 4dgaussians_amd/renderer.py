@@ -66,7 +66,7 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
     """-> (image, screenspace_points, visibility_filter, radii, depth), as the first five items of the
     reference's 7-tuple (renderer.py:221); with regularise=True the full 7-tuple (..., reg_dict, None): reg_dict holds
     the fine stage's momentum / scales / shs / knn_xyz / knn_long / knn_rot terms (:173-203; empty in the coarse
-    stage, :152-153), computed from the deformation at t - dt and t + dt -- ONE batched query of 2 P points here,
+    stage, :152-153), computed from the deformation at t - dt and t + dt -- ONE batched query of 3 P points (with the centre query) here,
     two calls in the reference -- and the k = min(100, P) nearest neighbours of the deformed positions.  shs_grad_hook(grad), if given, is called during the backward pass as soon
     as dL/d(deformed SH coefficients) exists, i.e. before the deformation backward runs (data-parallel training
     starts the all-reduce of the SH gradients there, parallel.GradBucket.early_reduce)."""
