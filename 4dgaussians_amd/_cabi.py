@@ -6,6 +6,7 @@ libgs4d.so raises at import of the operators that need it.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
 
@@ -38,8 +39,18 @@ def lib() -> C.CDLL:
         for name in ("gs4d_geometry_bytes", "gs4d_binning_bytes", "gs4d_image_bytes", "gs4d_backward_scratch_bytes",
                      "gs4d_l1_loss_scratch_bytes"):
             getattr(L, name).restype = C.c_size_t
+        L.gs4d_thread_state_release.restype = None
+        L.gs4d_mailbox_stats.restype = None
+        atexit.register(L.gs4d_thread_state_release)       # the main thread's pinned num_rendered mailbox
         _lib = L
     return _lib
+
+
+def mailbox_stats():
+    """(fast, slow): forwards of this thread whose num_rendered arrived through the mailbox / the copy + sync path."""
+    fast, slow = C.c_ulonglong(0), C.c_ulonglong(0)
+    lib().gs4d_mailbox_stats(C.byref(fast), C.byref(slow))
+    return fast.value, slow.value
 
 
 def check(rc: int, what: str) -> None:

@@ -4,17 +4,32 @@
 // Orchestration matched: RAST/cuda_rasterizer/rasterizer_impl.cu:198-339 (forward) and :343-444
 // (backward) of the reference, RAST = submodules/depth-diff-gaussian-rasterization.  Unlike the
 // reference, which launches on the legacy default stream, every launch goes to the stream the
-// caller passes.  The only global state is the opt-in stage timer below (off by default) and the
-// thread-local error string; one process per GPU stays independent.
+// caller passes.  Process-wide state: the opt-in stage timer below (off by default).  Per-thread state: the error
+// string and the forward's cached num_rendered mailbox (ThreadState).  One process per GPU stays independent.
 #include <stdarg.h>
 #include <stdio.h>
 
 #include <stdlib.h>
+#include <time.h>
 #include "gs4d_internal.h"
 
-int gs4d_launch_scan(int P, GeomState& g, uint32_t* mailbox, uint32_t seq, int debug, hipStream_t s);
+int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t seq, int debug, hipStream_t s);
 
 static thread_local char g_err[512] = "";
+
+// Per-THREAD cached state of gs4d_rasterize_forward (nothing is shared between threads or processes): the pinned
+// host mailbox the scan kernel posts num_rendered into, its sequence number, and the previous call's num_rendered
+// (the guess that sizes the binning chunk before the count is known).  Released by gs4d_thread_state_release().
+namespace {
+struct ThreadState {
+    unsigned long long* mailbox = nullptr;
+    bool tried = false;
+    uint32_t seq = 0;
+    size_t last_R = 0;
+    unsigned long long fast = 0, slow = 0;      // how often the count arrived through the mailbox / the copy + sync path
+};
+thread_local ThreadState t_state;
+}  // namespace
 
 void gs4d_set_error(const char* fmt, ...)
 {
@@ -176,7 +191,20 @@ static int sort_passes(int W, int H)
 extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
-int gs4d_abi_version(void) { return 5; }
+int gs4d_abi_version(void) { return 6; }
+
+void gs4d_thread_state_release(void)
+{
+    ThreadState& ts = t_state;
+    if (ts.mailbox) (void)hipHostFree(ts.mailbox);
+    ts = ThreadState();
+}
+
+void gs4d_mailbox_stats(unsigned long long* fast, unsigned long long* slow)
+{
+    if (fast) *fast = t_state.fast;
+    if (slow) *slow = t_state.slow;
+}
 
 void gs4d_profile_enable(int on)
 {
@@ -276,45 +304,68 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
                                     tan_fovx, tan_fovy, prefiltered, radii, g, debug, s);
     if (rc) return rc;
     // The one host round trip of the forward (rasterizer_impl.cu:282): num_rendered sizes the binning chunk.  The scan
-    // kernel posts it into a pinned host mailbox and the host spins on the sequence word -- a few microseconds instead
-    // of a D2H copy plus a stream synchronisation -- and the binning chunk is requested BEFORE the wait with the previous
-    // call's size plus 1/8 (the allocator callback runs Python), again afterwards only if that guess was too small.
-    static thread_local uint32_t* mailbox = nullptr;
-    static thread_local uint32_t mailbox_seq = 0;
-    static thread_local size_t last_R = 0;
-    static const bool use_mailbox = getenv("GS4D_NO_MAILBOX") == nullptr;
-    if (use_mailbox && !mailbox) {
+    // kernel posts ONE 64-bit word (sequence | prefilter flag, num_rendered) into a pinned, coherent host mailbox and the
+    // host polls it -- a few microseconds instead of a D2H copy plus a stream synchronisation -- for at most
+    // GS4D_MAILBOX_SPIN_US (default 5 ms) of wall clock; after that (a long queue ahead of this call, a shared or hung
+    // device) it takes the ordinary copy + synchronise path, which also reports a faulted stream.  The binning chunk is
+    // requested BEFORE the wait with the previous call's size plus 1/8 (the allocator callback runs Python), again
+    // afterwards only if that guess was too small.
+    ThreadState& ts = t_state;
+    if (!ts.tried) {
+        ts.tried = true;
         void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocPortable) == hipSuccess) {
-            mailbox = (uint32_t*)p;
-            mailbox[0] = mailbox[1] = mailbox[2] = 0;
+        if (getenv("GS4D_NO_MAILBOX") == nullptr &&
+            hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess) {
+            ts.mailbox = (unsigned long long*)p;
+            __atomic_store_n(ts.mailbox, 0ull, __ATOMIC_RELEASE);
         } else {
             (void)hipGetLastError();
         }
     }
-    const uint32_t seq = ++mailbox_seq ? mailbox_seq : ++mailbox_seq;       // never 0
-    rc = gs4d_launch_scan(P, g, mailbox, seq, debug, s);
+    ts.seq += 2;                                                            // even, bit 0 carries the prefilter flag
+    if (ts.seq == 0) ts.seq = 2;
+    const uint32_t seq = ts.seq;
+    rc = gs4d_launch_scan(P, g, ts.mailbox, seq, debug, s);
     if (rc) return rc;
 
     char* bchunk = nullptr;
     size_t guess_R = 0;
-    if (last_R) {
-        guess_R = last_R + last_R / 8 + 4096;
+    if (ts.last_R) {
+        guess_R = ts.last_R + ts.last_R / 8 + 4096;
         bchunk = (char*)binning_alloc(binning_ctx, BinningState::required(guess_R));
-        if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
+        if (!bchunk) {
+            (void)hipStreamSynchronize(s);                                  // no post may arrive after this call has returned
+            gs4d_set_error("binning allocator returned NULL");
+            return GS4D_EALLOC;
+        }
     }
 
     uint32_t host_counters[2] = {0, 0};
     bool posted = false;
-    if (mailbox) {
-        volatile uint32_t* mb = mailbox;
-        for (long spin = 0; spin < 400000000L; spin++) {                    // a few seconds at most, then the slow path
-            if (__atomic_load_n(&mb[2], __ATOMIC_ACQUIRE) == seq) { posted = true; break; }
+    if (ts.mailbox) {
+        static const long spin_us = [] { const char* e = getenv("GS4D_MAILBOX_SPIN_US"); long v = e ? atol(e) : 5000; return v < 0 ? 0L : v; }();
+        struct timespec t0;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned spin = 0;; spin++) {
+            const unsigned long long w = __atomic_load_n(ts.mailbox, __ATOMIC_ACQUIRE);   // one word: payload and sequence together
+            if ((uint32_t)(w >> 32 & ~1ull) == seq) {
+                host_counters[0] = (uint32_t)w;
+                host_counters[1] = (uint32_t)(w >> 32) & 1u;
+                posted = true;
+                break;
+            }
             __builtin_ia32_pause();
+            if ((spin & 127u) == 127u) {
+                struct timespec t1;
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) * 1000000L + (t1.tv_nsec - t0.tv_nsec) / 1000L >= spin_us) break;
+            }
         }
-        if (posted) { host_counters[0] = mb[0]; host_counters[1] = mb[1]; }
     }
-    if (!posted) {
+    if (posted) {
+        ts.fast++;
+    } else {
+        ts.slow++;
         GS4D_HIP_CHECK(hipMemcpyAsync(host_counters, g.counters, sizeof host_counters, hipMemcpyDeviceToHost, s));
         GS4D_HIP_CHECK(hipStreamSynchronize(s));
     }
@@ -333,7 +384,7 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
         bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R));
         if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
     }
-    last_R = (size_t)R;
+    ts.last_R = (size_t)R;
     BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
 
     rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);

@@ -18,12 +18,13 @@ namespace {
 // block_offsets = exclusive scan of block_sums (bits 0..30; bit 31 is the workgroup's prefilter flag); counters[0] =
 // total, counters[1] = OR of the flags (both words are written here: nothing clears them).  n is ceil(P/256)
 // (391 at P = 100k, 19.5k at P = 5M), so one 1024-lane workgroup looping over chunks is enough.
-// mailbox (may be null): three words of pinned host memory; the kernel posts (total, prefilter flag) and then the
-// sequence number the host is spinning on -- the host learns num_rendered without a stream synchronisation.
+// mailbox (may be null): one 64-bit word of pinned, coherent host memory; the kernel posts (seq | prefilter flag) << 32
+// | total with ONE system-scope release store -- payload and sequence number cannot be seen apart -- and the host,
+// polling that word, learns num_rendered without a stream synchronisation (seq is even, never 0).
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ block_sums,
                                                                uint32_t* __restrict__ block_offsets,
                                                                uint32_t* __restrict__ counters,
-                                                               uint32_t* __restrict__ mailbox, uint32_t seq)
+                                                               unsigned long long* __restrict__ mailbox, uint32_t seq)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
@@ -57,10 +58,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         counters[0] = s_carry;
         counters[1] = any_flag ? 1u : 0u;
         if (mailbox) {
-            mailbox[0] = s_carry;
-            mailbox[1] = any_flag ? 1u : 0u;
-            __threadfence_system();
-            __hip_atomic_store(&mailbox[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long word = ((unsigned long long)(seq | (any_flag ? 1u : 0u)) << 32) | (unsigned long long)s_carry;
+            __hip_atomic_store(mailbox, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
 }
@@ -561,7 +560,7 @@ int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_
     return GS4D_OK;
 }
 
-int gs4d_launch_scan(int P, GeomState& g, uint32_t* mailbox, uint32_t seq, int debug, hipStream_t s)
+int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t seq, int debug, hipStream_t s)
 {
     GS4D_PROF("scan", s);
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;

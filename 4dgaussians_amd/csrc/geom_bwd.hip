@@ -136,6 +136,7 @@ __device__ void gaussian_backward(const GeomBwdArgs& A, int idx, const float r[N
     A.dL_ddepth[idx] = r[3];
     A.dL_dmean2D[3 * idx + 0] = r[4];
     A.dL_dmean2D[3 * idx + 1] = r[5];
+    A.dL_dmean2D[3 * idx + 2] = 0.f;
     A.dL_dconic[4 * idx + 0] = r[6];
     A.dL_dconic[4 * idx + 1] = r[7];
     A.dL_dconic[4 * idx + 3] = r[8];
@@ -278,7 +279,12 @@ __device__ void gaussian_backward(const GeomBwdArgs& A, int idx, const float r[N
 __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= A.P || !(A.radii[idx] > 0)) return;
+    if (idx >= A.P) return;
+    if (!(A.radii[idx] > 0)) {
+        // dL_dmean2D is written in full (the caller may hand over uninitialised memory for it, see include/gs4d.h)
+        A.dL_dmean2D[3 * idx + 0] = 0.f; A.dL_dmean2D[3 * idx + 1] = 0.f; A.dL_dmean2D[3 * idx + 2] = 0.f;
+        return;
+    }
     const uint32_t cnt = A.tiles_touched[idx];
     if (cnt > GS4D_BIG_ROWS) {
         const uint32_t slot = atomicAdd(A.big_count, 1u);
@@ -287,12 +293,15 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
     }
     const uint32_t end = A.point_offsets[idx];
     const uint32_t first = end - cnt;
-    float r[NQ];
+    // The rows are summed in DOUBLE: the kernel waits on memory ~90 % of the time, so the wider adds are free, and the
+    // sums then carry only the rounding of the per-tile partials (the reference's float atomics add in arbitrary order;
+    // the oracle sums in double) -- dL_dscales / dL_drotations, derived through a cancelling chain, meet 1e-4 this way.
+    double r[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) r[q] = 0.f;
+    for (int q = 0; q < NQ; q++) r[q] = 0.0;
     const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
-    // The kernel waits on memory ~90 % of the time and every step of this walk is a dependent pair of gathers
-    // (inv -> row): four steps are issued together (16 loads in flight), summed in the same order as one by one.
+    // Every step of this walk is a dependent pair of gathers (inv -> row): four steps are issued together (16 loads
+    // in flight), summed in the same order as one by one.
     uint32_t s = first;
     for (; s + 4 <= end; s += 4) {
         uint32_t k[4];
@@ -315,7 +324,10 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
         r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
         r[8] += c.x; r[9] += c.y;
     }
-    gaussian_backward(A, idx, r);
+    float rf[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) rf[q] = (float)r[q];
+    gaussian_backward(A, idx, rf);
 }
 
 // One WAVE per deferred Gaussian (four per workgroup, no workgroup barriers): lane t sums rows first+t, first+t+64, ...,
@@ -330,9 +342,9 @@ __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
         const uint32_t cnt = A.tiles_touched[idx];
         const uint32_t end = A.point_offsets[idx];
         const uint32_t first = end - cnt;
-        float r[NQ];
+        double r[NQ];
 #pragma unroll
-        for (int q = 0; q < NQ; q++) r[q] = 0.f;
+        for (int q = 0; q < NQ; q++) r[q] = 0.0;
         const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
         for (uint32_t s = first + lane; s < end; s += 64) {
             const uint32_t k = A.inv[s];
@@ -344,7 +356,10 @@ __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
 #pragma unroll
         for (int q = 0; q < NQ; q++)
             for (int off = 32; off >= 1; off >>= 1) r[q] += __shfl_xor(r[q], off, 64);
-        if (lane == 0) gaussian_backward(A, idx, r);
+        float rf[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; q++) rf[q] = (float)r[q];
+        if (lane == 0) gaussian_backward(A, idx, rf);
     }
 }
 

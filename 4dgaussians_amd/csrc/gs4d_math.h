@@ -149,19 +149,23 @@ __device__ __forceinline__ Mat3 scale_columns(const float3 s)
 // alpha >= 1/255  <=>  0.5 (cx dx^2 + 2 cy dx dy + cz dy^2) <= t,  t = ln(255 opacity); the ellipse's
 // half extents are sqrt(2 t cz / det) and sqrt(2 t cx / det), det = cx cz - cy^2.  The box is inflated
 // (0.1 % + 0.05 px) so float rounding in the kernels' own alpha can never disagree with it; a splat
-// that cannot reach 1/255 anywhere gets an empty box.  Returns (x - hx, x + hx, y - hy, y + hy).
+// that cannot reach 1/255 anywhere (t < 0) gets an empty box.  Anything NaN (opacity, conic, mean) or degenerate gets
+// the never-cull box: the reference's tests `power > 0` and `alpha < 1/255` are both false for NaN, so it BLENDS such
+// a splat and the NaN reaches the image -- a diverged model must stay visible here too.
+// Returns (x - hx, x + hx, y - hy, y + hy).
 __device__ __forceinline__ float4 alpha_support_box(float2 xy, float4 conic_opacity)
 {
     const float cx = conic_opacity.x, cy = conic_opacity.y, cz = conic_opacity.z;
+    const float4 never_cull = make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);
     const float t = logf(255.0f * conic_opacity.w);
+    if (t < 0.0f) return make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
     const float det = cx * cz - cy * cy;
-    if (!(t > 0.0f) || !(det > 0.0f)) {
-        if (t > 0.0f) return make_float4(-3.0e38f, 3.0e38f, -3.0e38f, 3.0e38f);   // degenerate conic: never cull
-        return make_float4(3.0e38f, -3.0e38f, 3.0e38f, -3.0e38f);
-    }
+    if (!(t >= 0.0f) || !(det > 0.0f)) return never_cull;                 // NaN opacity / NaN or degenerate conic
     const float k = 2.0f * t / det;
     const float hx = sqrtf(k * cz) * 1.001f + 0.05f, hy = sqrtf(k * cx) * 1.001f + 0.05f;
-    return make_float4(xy.x - hx, xy.x + hx, xy.y - hy, xy.y + hy);
+    const float4 box = make_float4(xy.x - hx, xy.x + hx, xy.y - hy, xy.y + hy);
+    if (!(box.x <= box.y) || !(box.z <= box.w)) return never_cull;         // NaN mean or extent
+    return box;
 }
 
 }  // namespace gs4d

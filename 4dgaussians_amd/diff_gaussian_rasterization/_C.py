@@ -40,8 +40,13 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
     P, H, W = means3D.size(0), int(image_height), int(image_width)
     # With P != 0 the forward writes every pixel (blend) and every radius (preprocess): no clearing fill.  With no
     # points the library returns at once (rasterize_points.cu:82) and the zero-initialised outputs are the result.
-    out_color, out_depth, radii = _cabi.zeros_group(device, (NUM_CHANNELS, H, W), (1, H, W), (P,),
-                                                    dtypes=(torch.float32, torch.float32, torch.int32), _fill=(P == 0))
+    # The three tensors escape to the caller, so each is an allocation of its own as in the reference
+    # (rasterize_points.cu:68-70): views of one block would make autograd refuse in-place ops on them
+    # (image.clamp_()) and would keep the whole block alive through any one of them.
+    make = torch.zeros if P == 0 else torch.empty
+    out_color = make((NUM_CHANNELS, H, W), dtype=torch.float32, device=device)
+    out_depth = make((1, H, W), dtype=torch.float32, device=device)
+    radii = make((P,), dtype=torch.int32, device=device)
     geom, binning, img = (_cabi.TensorAllocator(device) for _ in range(3))
     rendered = C.c_int(0)
     if P != 0:
@@ -76,9 +81,13 @@ def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rot
     P = means3D.size(0)
     H, W = dL_dout_color.size(1), dL_dout_color.size(2)
     M = sh.size(1) if sh.numel() != 0 else 0
-    (dL_dmeans3D, dL_dmeans2D, dL_dcolors, dL_ddepths, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales,
-     dL_drotations) = _cabi.zeros_group(device, (P, 3), (P, 3), (P, NUM_CHANNELS), (P, 1), (P, 2, 2), (P, 1), (P, 6),
+    (dL_dmeans3D, dL_dcolors, dL_ddepths, dL_dconic, dL_dopacity, dL_dcov3D, dL_dsh, dL_dscales,
+     dL_drotations) = _cabi.zeros_group(device, (P, 3), (P, NUM_CHANNELS), (P, 1), (P, 2, 2), (P, 1), (P, 6),
                                         (P, M, 3), (P, 3), (P, 4))
+    # dL_dmeans2D becomes viewspace_point_tensor.grad, which the densifier keeps per view (train.py:231-233): its own
+    # allocation, so that it does not pin the ~76 P floats of the block above.  The per-Gaussian kernel writes all of
+    # its 3 P elements whenever it runs (R > 0), so it only needs clearing when nothing was rendered.
+    dL_dmeans2D = (torch.zeros if (P == 0 or int(R) == 0) else torch.empty)((P, 3), dtype=torch.float32, device=device)
     if P != 0:
         keep = [_dev_f32(t, device) for t in (background, means3D, sh, colors, scales, rotations, cov3D_precomp,
                                                 viewmatrix, projmatrix, campos, dL_dout_color, dL_dout_depth)]

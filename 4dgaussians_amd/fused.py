@@ -35,7 +35,8 @@ class _Activate(torch.autograd.Function):
         if s_.shape != (P, 3) or r_.shape != (P, 4) or o_.numel() != P:
             raise RuntimeError("activate expects log_scales [P,3], rotations [P,4], opacity [P,1]")
         dev = s_.device
-        scales, rot_n, opacity = _cabi.empty_group(dev, (P, 3), (P, 4), tuple(o_.shape))
+        # outputs escape to the caller: separate allocations (views of one block would make autograd refuse in-place ops)
+        scales, rot_n, opacity = (torch.empty(shp, dtype=torch.float32, device=dev) for shp in ((P, 3), (P, 4), tuple(o_.shape)))
         with torch.cuda.device(dev):
             rc = L.gs4d_activate_forward(C.c_int(P), _cabi.ptr(s_), _cabi.ptr(r_), _cabi.ptr(o_), _cabi.ptr(scales),
                                          _cabi.ptr(rot_n), _cabi.ptr(opacity), _cabi.current_stream(dev))
@@ -73,13 +74,14 @@ class _L1Loss(torch.autograd.Function):
         dev = a_.device
         n = a_.numel()
         nscratch = int(L.gs4d_l1_loss_scratch_bytes()) // 4
-        buf = torch.empty(nscratch + 1, dtype=torch.float32, device=dev)
+        buf = torch.empty(nscratch, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)      # its own tensor: callers do `loss += reg`
         with torch.cuda.device(dev):
             rc = L.gs4d_l1_loss_forward(C.c_size_t(n), _cabi.ptr(a_), _cabi.ptr(b_), _cabi.ptr(buf),
-                                        C.c_void_p(buf.data_ptr() + 4 * nscratch), _cabi.current_stream(dev))
+                                        _cabi.ptr(loss), _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_l1_loss_forward")
         ctx.save_for_backward(a_, b_)
-        return buf[nscratch]
+        return loss
 
     @staticmethod
     def backward(ctx, g):

@@ -278,7 +278,8 @@ class Deformation(nn.Module):
         return self.grid.get_aabb
 
     def set_aabb(self, xyz_max, xyz_min):
-        self.grid.set_aabb(xyz_max, xyz_min)
+        self.grid.set_aabb(xyz_max, xyz_min)      # replaces grid.aabb by a new Parameter: the cached plan is stale
+        self._step_cache = None
 
     def create_net(self):
         W = self.W
@@ -330,6 +331,11 @@ class Deformation(nn.Module):
                     use_time=int(bool(a.use_time)), use_force=int(bool(a.use_force)),
                     data_grad_hook=self.data_grad_hook)
 
+    def _flags(self):
+        a = self.args
+        return (bool(a.no_dx), bool(a.no_ds), bool(a.no_dr), bool(a.no_dshs), bool(a.apply_rotation), bool(a.use_time),
+                bool(a.use_force), bool(a.no_do), self.blend_time_force)
+
     def _params(self):
         planes = [p for level in self.grid.grids for p in level]
         trunk = []
@@ -354,12 +360,16 @@ class Deformation(nn.Module):
         if prev_frames is not None:
             raise NotImplementedError("prev_frames conditioning is outside the hot path (SURVEY.md section 8)")
         cache = self.__dict__.get("_step_cache")
-        if cache is None or not cache[1]["plan"].matches(cache[0]):
+        # The cached plan is valid while (a) every cached parameter keeps its storage, (b) the aabb Parameter is still
+        # the cached object (HexPlaneField.set_aabb installs a new one) and (c) the switches read from `args` are
+        # unchanged (enable_extra_deform / disable_extra_deform or a direct assignment).
+        if (cache is None or cache[2] != self._flags() or self.grid.aabb is not cache[3]
+                or not cache[1]["plan"].matches(cache[0])):
             params = self._params()
             cfg = self._config()
             cfg["plan"] = _Plan(cfg, params)
-            cache = self.__dict__["_step_cache"] = (params, cfg)
-        params, cfg = cache
+            cache = self.__dict__["_step_cache"] = (params, cfg, self._flags(), self.grid.aabb)
+        params, cfg = cache[0], cache[1]
         cfg["data_grad_hook"] = self.data_grad_hook
         out = _DeformFunction.apply(points, scales, rotations, shs, time, force, cfg, *params)
         # opacity passes through (no_do): the reference's opacity[:, :1] is the tensor itself when it is (P, 1)
@@ -373,9 +383,11 @@ class Deformation(nn.Module):
 
     def enable_extra_deform(self):
         self.args.no_ds = self.args.no_dr = self.args.no_dshs = False
+        self._step_cache = None
 
     def disable_extra_deform(self):
         self.args.no_ds = self.args.no_dr = self.args.no_dshs = True
+        self._step_cache = None
 
 
 def initialize_weights(m):

@@ -16,6 +16,7 @@ import torch
 from .. import _cabi
 
 SMOOTHNESS, L1, L2 = 0, 1, 2
+MAX_TERMS = 32                                       # terms per gs4d_plane_reg_* call (REG_MAX_TERMS, csrc/train_step.hip)
 PLANE_GRIDS, TIME_GRIDS = (0, 1, 3), (2, 4, 5)      # scene/gaussian_model.py: self.plane_grids / self.time_grids
 
 
@@ -38,14 +39,15 @@ class _PlaneReg(torch.autograd.Function):
             p = mem[i]
             t.plane, t.grad, t.C, t.H, t.W, t.kind, t.weight = p.data_ptr(), None, p.shape[1], p.shape[2], p.shape[3], kind, w
         nscratch = int(L.gs4d_plane_reg_scratch_bytes()) // 4
-        buf = torch.empty(nscratch + 1, dtype=torch.float32, device=dev)
+        buf = torch.empty(nscratch, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)       # its own tensor: callers do `loss += reg`
         with torch.cuda.device(dev):
-            rc = L.gs4d_plane_reg_forward(C.c_int(len(kinds_weights)), terms, _cabi.ptr(buf),
-                                          C.c_void_p(buf.data_ptr() + 4 * nscratch), _cabi.current_stream(dev))
+            rc = L.gs4d_plane_reg_forward(C.c_int(len(kinds_weights)), terms, _cabi.ptr(buf), _cabi.ptr(loss),
+                                          _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_plane_reg_forward")
         ctx.kinds_weights = kinds_weights
         ctx.save_for_backward(*mem)
-        return buf[nscratch]
+        return loss
 
     @staticmethod
     def backward(ctx, g):
@@ -75,7 +77,12 @@ def plane_regulation(planes, kinds_weights):
     kinds_weights = tuple((int(i), int(k), float(w)) for i, k, w in kinds_weights)
     if not kinds_weights:
         return torch.zeros((), device=planes[0].device)
-    return _PlaneReg.apply(kinds_weights, *planes)
+    # one call takes at most MAX_TERMS terms: 3 multires levels with all four weights on are 36, 4 levels 48
+    total = None
+    for lo in range(0, len(kinds_weights), MAX_TERMS):
+        part = _PlaneReg.apply(kinds_weights[lo:lo + MAX_TERMS], *planes)
+        total = part if total is None else total + part
+    return total
 
 
 def compute_plane_smoothness(t):

@@ -14,10 +14,13 @@ Scaling is weak: every rank renders its own view of the same scene each step (vi
 `--mode fps` times render_for_image (deformation forward + rasterizer forward, no grad) instead.
 
 One JSON line is printed by rank 0.  Besides the contract fields it carries
-  roofline      -- for the dominant kernel (blend_backward): algorithmic bytes per launch / its
-                   average duration measured with HIP events on the launch stream in the timed region
+  roofline      -- for the dominant kernel (blend_backward, fp32-VALU bound): SURVEY 8(d)'s flops per (pixel, Gaussian)
+                   pair x pairs per launch / its average duration measured with HIP events on the launch stream in the
+                   timed region, against the fp32 vector peak; the HBM view of the same launch under "hbm"
+  render_fps    -- (train mode) BASELINE.json's second metric from the same run: render_for_image frames/s with the
+                   blend_forward roofline
   cpu_baseline  -- the CPU oracle (scalar C rasterizer + PyTorch-CPU deformation) on one core for the
-                   same workload, rank 0 / N == 1 only
+                   same workload, rank 0 / N == 1 only; host core count / CPU model and the all-core deformation time beside it
   stages_ms     -- average device milliseconds of every kernel stage (same HIP-event mechanism)
   with_optimizer -- (train mode) the same iteration plus the HexPlane grid regularisers in the loss and one fused
                    AdamW step over all parameters ("report optimizer-inclusive separately"),
@@ -51,23 +54,6 @@ STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "preprocess", "
           "activate_backward", "mlp_backward", "hexplane_backward", "weight_grads", "plane_reg_forward", "plane_reg_backward", "adamw")
 
 
-def deform_args(name: str):
-    """Shape-matched deformation configs: mutant-shaped for C1-C4, force_blend-shaped for C5."""
-    a = types.SimpleNamespace(
-        net_width=64, defor_depth=0, posebase_pe=10, scale_rotation_pe=2, opacity_pe=2, grid_pe=0, force_pe=2,
-        time_pe=2, bounds=1.6, multires=[1, 2], no_dx=False, no_ds=False, no_dr=False, no_do=True, no_dshs=False,
-        empty_voxel=False, static_mlp=False, apply_rotation=True, use_time=True, use_force=False,
-        blend_time_force=True, prev_frames=0, no_grid=False,
-        kplanes_config={"grid_dimensions": 2, "input_coordinate_dim": 4, "output_coordinate_dim": 32,
-                        "resolution": [64, 64, 64, 75]})
-    if name in ("C3", "C4"):
-        a.kplanes_config["resolution"] = [64, 64, 64, 150]
-    if name == "C5":
-        a.kplanes_config.update(output_coordinate_dim=128, resolution=[64, 64, 64, 256])
-        a.defor_depth, a.force_pe, a.time_pe, a.use_force = 5, 4, 4, True
-    return a
-
-
 _T0 = time.perf_counter()
 
 
@@ -91,6 +77,7 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-pass", action="store_true", help="skip the separate optimizer-inclusive timing loop")
+    ap.add_argument("--no-fps-pass", action="store_true", help="(train mode) skip the render-FPS loop that fills `render_fps`")
     ap.add_argument("--no-stage-events", action="store_true",
                     help="do not record per-stage HIP events in the timed region (then no roofline / stages_ms)")
     args = ap.parse_args()
@@ -119,58 +106,35 @@ def main():
 
     syn = importlib.import_module("4dgaussians_amd.synthetic")
     R = importlib.import_module("4dgaussians_amd.renderer")
-    Dm = importlib.import_module("4dgaussians_amd.scene.deformation")
+    Wl = importlib.import_module("4dgaussians_amd.workload")
     par = importlib.import_module("4dgaussians_amd.parallel")
     F = importlib.import_module("4dgaussians_amd.fused")
     cabi = importlib.import_module("4dgaussians_amd._cabi")
     L = cabi.lib()
+    if dp and not rehearse and dist.get_world_size() != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={dist.get_world_size()}: "
+                         "start it as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`")
+    if not dp and args.gpus != 1:
+        raise SystemExit(f"bench.py --gpus {args.gpus} needs one process per GPU (torch.distributed.run); got a single process")
 
-    cfg = syn.CONFIGS[args.config]
-    _, cam0, raw = syn.make_workload(args.config, P=args.P)
-    P = raw["xyz"].shape[0]
-    W, H = cfg["W"], cfg["H"]
-    torch.manual_seed(syn.seed_for(args.config))
-    pc = R.GaussianParams(raw, dev)
-    deform = Dm.deform_network(deform_args(args.config))
-    deform.deformation_net.set_aabb([1.3, 1.3, 1.3], [-1.3, -1.3, -1.3])
-    deform = deform.to(dev)
+    # the scene every rank holds (identical seeds -> identical replicas) and this rank's view of it; the parity tests
+    # build the same thing through the same function (tests/test_gpu_c2.py)
+    scene = Wl.build_scene(args.config, dev, P=args.P, rank=rank, calibrate=False)
+    pc, deform, cam, cam_np, bg, target = (scene[k] for k in ("pc", "deform", "cam", "cam_np", "bg", "target"))
+    P, W, H = scene["P"], scene["W"], scene["H"]
     if dp:  # replicas start identical
         par.GradBucket.exchange_in_world_of_one = rehearse
         for p in list(pc.parameters()) + list(deform.parameters()):
             dist.broadcast(par._memory_order_view(p.data), 0)      # a contiguous 1-D view, also of channels-last planes
     _dbg("parameters replicated")
-    # each rank looks at the scene from its own azimuth / timestamp (view-parallel)
-    rng = np.random.default_rng(1234 + rank)
-    cam_np = syn.look_at_camera(W, H, azimuth=0.7 + 0.6 * rank)
-    cam = R.Camera(cam_np, dev, time=float(rng.uniform(0, 1)), force=0.0)
-    bg = torch.ones(3, device=dev)
-    target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank))
     Craw = importlib.import_module("4dgaussians_amd.diff_gaussian_rasterization")._C
 
     def rasterize_untimed():
-        """One untimed forward through the C-level API -> (num_rendered, state buffers): workload statistics."""
-        with torch.no_grad():
-            m3, sc, rot, op, sh = deform.forward_dynamic(pc._xyz, pc._scaling, pc._rotation, pc._opacity, pc._features,
-                                                         torch.full((P, 1), cam.time, device=dev),
-                                                         torch.zeros(P, 1, device=dev), None)
-            e = torch.Tensor([])
-            return Craw.rasterize_gaussians(
-                bg, m3, e, torch.sigmoid(op), torch.exp(sc), torch.nn.functional.normalize(rot), 1.0, e,
-                cam.world_view_transform, cam.full_proj_transform, cam_np.tanfovx, cam_np.tanfovy, H, W, sh, 3,
-                cam.camera_center, False, False)
+        return Wl.rasterize_untimed(pc, deform, cam, cam_np, bg)
 
-    # SURVEY.md 8(d): s0 is chosen per config so that the RENDERED scene has ~8 tiles per Gaussian.  The
-    # random-init deformation heads shift the log-scales, so s0 is calibrated on the deformed scene: a uniform
-    # log-scale offset found by a few fixed-point steps on rank 0's view (tiles ~ scale^2), applied on every rank.
-    log_s0_offset = 0.0
-    for _ in range(8):
-        ratio = rasterize_untimed()[0] / P
-        if abs(ratio - 8.0) < 0.2 or ratio == 0:
-            break
-        d = 0.5 * float(np.log(8.0 / ratio))
-        log_s0_offset += d
-        with torch.no_grad():
-            pc._scaling.add_(d)
+    # ~8 tiles per Gaussian on the DEFORMED scene (workload.calibrate_log_scale_offset); with several
+    # ranks the offset found on rank 0's view is applied everywhere
+    log_s0_offset = Wl.calibrate_log_scale_offset(pc, deform, cam, cam_np, bg)
     if dp:
         off = torch.tensor([log_s0_offset], dtype=torch.float64, device=dev)
         dist.broadcast(off, 0)
@@ -178,7 +142,7 @@ def main():
             pc._scaling.add_(float(off.item()) - log_s0_offset)
         log_s0_offset = float(off.item())
     _dbg(f"scene calibrated, offset {log_s0_offset:.4f}")
-    raw = dict(raw, log_scales=(raw["log_scales"] + np.float32(log_s0_offset)).astype(np.float32))
+    raw = dict(scene["raw"], log_scales=pc._scaling.detach().cpu().numpy().copy())
     all_params = list(pc.parameters()) + list(deform.parameters())
     # ONE flat bucket for the Gaussian and the deformation gradients, exchanged in three pieces that overlap with the
     # backward pass: (1) the SH gradients are final when the rasterizer's backward has run (tensor hook), (2) position /
@@ -187,12 +151,18 @@ def main():
     planes = [p for level in deform.deformation_net.grid.grids for p in level]
     ft = deform.deformation_net.force_time_embed
     data_params = [pc._xyz, pc._scaling, pc._rotation, *planes, ft.weight, ft.bias]
-    comm, collectives = None, "torch.distributed"
+    comm, collectives, collectives_fallback = None, "torch.distributed", None
     if dp and dist.get_backend() == "nccl" and not os.environ.get("GS4D_BENCH_TORCH_COLLECTIVES"):
         try:                                    # collective: all ranks succeed or all fall back together
             comm, collectives = par.RcclComm(dev), "ncclAllReduce on a side stream (parallel.RcclComm)"
         except RuntimeError as e:
+            # not silent: the line carries "collectives_fallback" with the reason, and GS4D_BENCH_STRICT_COLLECTIVES=1
+            # turns it into a non-zero exit (the collectives are RCCL either way: torch's "nccl" backend)
+            collectives_fallback = str(e)
             print(f"[bench rank {rank}] direct RCCL communicator unavailable, using torch.distributed collectives: {e}", file=sys.stderr)
+            if os.environ.get("GS4D_BENCH_STRICT_COLLECTIVES"):
+                dist.destroy_process_group()
+                raise SystemExit(3)
     _dbg(f"gradient exchange through {collectives}")
     bucket = par.GradBucket(all_params, early=[pc._features, *data_params], comm=comm)
     dp_hooks = os.environ.get("GS4D_BENCH_DP_HOOKS", "all")       # experiments: "all" | "shs" | "none"
@@ -281,6 +251,30 @@ def main():
         stages = read_stages()
         stages.update(timed)
 
+    # render FPS (BASELINE.json's second metric; definition render.py:58-77 without the to8b D2H copy) in the SAME
+    # default run, so that the driver's line carries it: render_for_image = deformation forward + rasterizer forward
+    # under no_grad, timed between synchronisations like the train loop, blend_forward bracketed by HIP events
+    fps_dt, fps_frames, fps_blend_ms = None, 0, None
+    if args.mode == "train" and not args.no_fps_pass:
+        for _ in range(max(3, args.warmup)):
+            fps_step()
+        sync()
+        L.gs4d_profile_reset()
+        L.gs4d_profile_select(None if args.no_stage_events else b"blend_forward")
+        L.gs4d_profile_enable(0 if args.no_stage_events else 1)
+        fps_frames = max(100, 5 * args.steps)
+        t0 = time.perf_counter()
+        for _ in range(fps_frames):
+            fps_step()
+        sync()
+        fps_dt = time.perf_counter() - t0
+        L.gs4d_profile_enable(0)
+        fps_blend_ms = read_stages().get("blend_forward")
+        if dp:
+            t = torch.tensor([fps_dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            fps_dt = float(t.item())
+
     if rank == 0:
         # workload statistics for the roofline numerators (one extra untimed forward through the C-level API)
         with torch.no_grad():
@@ -293,41 +287,51 @@ def main():
             tile_max = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
             pairs_bwd = int(tile_max.sum().item()) * 256        # (pixel, Gaussian) pairs the backward evaluates
         def pmc_traffic(kernel_prefix):
-            """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+            """(HBM bytes per launch, source file) of a kernel from this round's committed rocprofv3 PMC passes
+            (profiles/r02_pmc_traffic.json, written by tools/profile_round.sh from separate FETCH_SIZE / WRITE_SIZE
+            runs of this same command), or (None, None) for another workload or when the file is absent."""
+            path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
             try:
-                d = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic_v11.json")))
+                d = json.load(open(path))
                 for k, v in d["kernels"].items():
                     if k.startswith(kernel_prefix) and args.config == "C2" and args.P is None:
-                        return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
+                        return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0, os.path.relpath(path, ROOT)
             except (OSError, KeyError, ValueError):
                 pass
-            return None
+            return None, None
+
+        def blend_roofline(kernel, stage_ms, alg_bytes, flop_per_pair):
+            """Both blend kernels are bound by fp32 VALU issue (PMC: VALU busy ~76 %, MFMA pipe idle,
+            HBM at a few per cent), so `bound` / `frac` are quoted against the fp32 vector peak with SURVEY 8(d)'s
+            per-pair flop figure; the HBM view of the same launch is kept beside it."""
+            sec = stage_ms * 1e-3
+            tf = pairs_bwd * flop_per_pair / sec / 1e12
+            traffic, src = pmc_traffic(kernel)
+            return {"kernel": kernel, "bound": "valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+                    "avg_launch_ms": round(stage_ms, 4), "pairs": pairs_bwd, "flop_per_pair": flop_per_pair,
+                    "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / sec / 1e9, 2),
+                            "peak_GBps": HBM_PEAK_GBS, "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 5)},
+                    "note": "pairs = sum over tiles of 256 x (list entries up to the tile's last contributor); "
+                            "flop_per_pair from SURVEY.md 8(d); peak = fp32 vector / f32-MFMA 157.3 TFLOP/s"}
 
         roofline = None
         if args.mode == "train" and "blend_backward" in stages:
             # SURVEY.md 8(d): 44 B/instance staged + 40 B/instance gradient rows + 24 B/pixel (dL/dcolor 12, dL/ddepth 4, final_T 4, n_contrib 4)
-            alg_bytes = 84.0 * Rn + 24.0 * W * H
-            sec = stages["blend_backward"] * 1e-3
-            achieved = alg_bytes / sec / 1e9
-            roofline = {"kernel": "blend_backward_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("blend_backward_kernel"),
-                        "traffic_note": "bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from profiles/r01_pmc_traffic_v11.json (separate rocprofv3 --pmc passes)",
-                        "avg_launch_ms": round(stages["blend_backward"], 4), "algorithmic_bytes": alg_bytes,
-                        "note": "kernel is fp32-VALU/LDS bound, not HBM bound: see valu_* fields",
-                        "valu_pairs": pairs_bwd, "valu_flop_per_pair": 60,
-                        "valu_achieved_tflops": round(pairs_bwd * 60 / sec / 1e12, 3), "valu_peak_tflops": FP32_PEAK_TFLOPS,
-                        "valu_frac": round(pairs_bwd * 60 / sec / 1e12 / FP32_PEAK_TFLOPS, 4)}
+            roofline = blend_roofline("blend_backward_kernel", stages["blend_backward"], 84.0 * Rn + 24.0 * W * H, 60)
         elif "blend_forward" in stages:
-            alg_bytes = 44.0 * Rn + 24.0 * W * H
-            sec = stages["blend_forward"] * 1e-3
-            achieved = alg_bytes / sec / 1e9
-            roofline = {"kernel": "blend_forward_kernel", "bound": "hbm", "achieved": round(achieved, 2),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic("blend_forward_kernel"),
-                        "avg_launch_ms": round(stages["blend_forward"], 4), "algorithmic_bytes": alg_bytes}
+            roofline = blend_roofline("blend_forward_kernel", stages["blend_forward"], 44.0 * Rn + 24.0 * W * H, 25)
+
+        render_fps = None
+        if fps_dt is not None:
+            render_fps = {"metric": "render FPS", "value": round(world * fps_frames / fps_dt, 2), "unit": "frames/s",
+                          "ms_per_frame": round(fps_dt / fps_frames * 1e3, 4), "frames": fps_frames, "n_gpus": world,
+                          "what": f"render_for_image (deformation forward + rasterizer forward, no grad) of the same scene at {W}x{H}",
+                          "roofline": blend_roofline("blend_forward_kernel", fps_blend_ms, 44.0 * Rn + 24.0 * W * H, 25) if fps_blend_ms else None}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, syn, raw, cam_np, cam.time, deform, target.cpu().numpy())
+            cpu = cpu_baseline(args, raw, cam_np, cam.time, deform, target.cpu().numpy())
 
         unit = "view-iterations/s (fwd+bwd)" if args.mode == "train" else "frames/s"
         metric = "train iters/sec (fwd+bwd)" if args.mode == "train" else "render FPS"
@@ -340,8 +344,9 @@ def main():
                                    f"1 view per GPU per step", "global_batch_views": world,
                        "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
                        "log_s0_offset": round(log_s0_offset, 4),
-                       "grad_allreduce_bytes": bucket.nbytes, "collectives": collectives if dp else None},
-            "roofline": roofline, "cpu_baseline": cpu,
+                       "grad_allreduce_bytes": bucket.nbytes, "collectives": collectives if dp else None,
+                       "collectives_fallback": collectives_fallback},
+            "roofline": roofline, "cpu_baseline": cpu, "render_fps": render_fps,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
         }
@@ -447,43 +452,57 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, syn, raw, cam_np, t_view, deform, target):
-    """The CPU oracle on ONE core: PyTorch-CPU deformation restatement + scalar C rasterizer, one full
-    iteration of the same workload (forward only for --mode fps).  Reported, never used as the product."""
-    from oracle import deformation_ref as DR
-    from oracle import rasterizer_oracle as RO
-    torch.set_num_threads(1)
-    a = deform.deformation_net.args
-    kc = a.kplanes_config
-    cfg = DR.DeformConfig(net_width=a.net_width, defor_depth=a.defor_depth, posebase_pe=a.posebase_pe,
-                          scale_rotation_pe=a.scale_rotation_pe, force_pe=a.force_pe, time_pe=a.time_pe,
-                          plane_channels=kc["output_coordinate_dim"], resolution=list(kc["resolution"]),
-                          multires=list(a.multires), use_time=a.use_time, use_force=a.use_force)
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(args, raw, cam_np, t_view, deform, target):
+    """The CPU oracle (oracle/compose.py: PyTorch-CPU deformation restatement + scalar C rasterizer) on ONE core: one
+    full iteration of the same workload (forward only for --mode fps), plus -- SURVEY.md 8(d) -- the deformation
+    part alone on all the cores this process may use.  Reported, never used as the product."""
+    from oracle import compose
     train = args.mode == "train"
-    sd = {k: v.detach().cpu().contiguous().requires_grad_(train and v.dtype == torch.float32 and "poc" not in k and "aabb" not in k)
-          for k, v in deform.state_dict().items()}
+    cfg = compose.config_from_args(deform.deformation_net.args)
+    sd = deform.state_dict()
     P = raw["xyz"].shape[0]
-    x = {k: torch.from_numpy(raw[k]).requires_grad_(train) for k in ("xyz", "log_scales", "rot", "opacity_logit", "sh")}
-    t0 = time.perf_counter()
-    with torch.set_grad_enabled(train):
-        m3, sc, rot, op, sh = DR.forward_dynamic(sd, cfg, x["xyz"], x["log_scales"], x["rot"], x["opacity_logit"], x["sh"],
-                                                 torch.full((P, 1), float(t_view)), torch.zeros(P, 1))
-        sc_a, rot_a, op_a = torch.exp(sc), torch.nn.functional.normalize(rot), torch.sigmoid(op)
-    f = RO.forward(np.ones(3, np.float32), m3.detach().numpy(), None, op_a.detach().numpy(), sc_a.detach().numpy(),
-                   rot_a.detach().numpy(), 1.0, None, cam_np.viewmatrix, cam_np.projmatrix, cam_np.tanfovx, cam_np.tanfovy,
-                   cam_np.image_height, cam_np.image_width, sh.detach().numpy(), 3, cam_np.campos)
-    if train:
-        gc = (np.sign(f["color"] - target) / target.size).astype(np.float32)
-        g = RO.backward(f, gc, np.zeros((1, cam_np.image_height, cam_np.image_width), np.float32))
-        tg = lambda k, shape: torch.from_numpy(g[k].reshape(shape))
-        torch.autograd.backward([m3, sc_a, rot_a, op_a, sh],
-                                [tg("dL_dmeans3D", m3.shape), tg("dL_dscales", sc_a.shape), tg("dL_drotations", rot_a.shape),
-                                 tg("dL_dopacity", op_a.shape), tg("dL_dsh", sh.shape)])
-    sec = time.perf_counter() - t0
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    threads_all = max(1, min(affinity, int(os.environ.get("OMP_NUM_THREADS", affinity))))
+    torch.set_num_threads(1)
+    one = compose.step(cfg, sd, raw, cam_np, t_view, target=target, train=train)
+    sec = one["seconds"]
+    # the deformation field alone (forward, and backward from random upstream gradients) on one and on all cores
+    from oracle import deformation_ref as DR
+
+    def deformation_only(threads):
+        torch.set_num_threads(threads)
+        sdg = {k: v.detach().cpu().contiguous().clone().requires_grad_(train and v.dtype == torch.float32 and "poc" not in k and "aabb" not in k)
+               for k, v in sd.items()}
+        x = [torch.from_numpy(raw[k]).clone().requires_grad_(train) for k in ("xyz", "log_scales", "rot", "opacity_logit", "sh")]
+        t0 = time.perf_counter()
+        with torch.set_grad_enabled(train):
+            outs = DR.forward_dynamic(sdg, cfg, *x, torch.full((P, 1), float(t_view)), torch.zeros(P, 1))
+            if train:
+                torch.autograd.backward([outs[0], outs[1], outs[2], outs[4]],
+                                        [torch.ones_like(outs[0]), torch.ones_like(outs[1]), torch.ones_like(outs[2]), torch.ones_like(outs[4])])
+        return time.perf_counter() - t0
+
+    d1 = deformation_only(1)
+    dall = deformation_only(threads_all)
+    torch.set_num_threads(threads_all)
+    what = "fwd+bwd iteration" if train else "frame"
     return {"value": round(1.0 / sec, 5), "unit": "view-iterations/s (fwd+bwd)" if train else "frames/s", "cores": 1,
             "kind": "port", "seconds": round(sec, 2),
-            "sample": f"one full {'fwd+bwd iteration' if train else 'frame'} of the same workload (P={P}, "
-                      f"{cam_np.image_width}x{cam_np.image_height}) on 1 thread: oracle/deformation_ref.py + oracle/rasterizer_ref.c"}
+            "sample": f"one full {what} of the same workload (P={P}, {cam_np.image_width}x{cam_np.image_height}) on 1 thread: "
+                      "oracle/compose.py = oracle/deformation_ref.py + oracle/rasterizer_ref.c",
+            "host": {"nproc": os.cpu_count(), "usable_cores": affinity, "cpu_model": cpu_model()},
+            "deformation_only": {"what": f"deformation field {'fwd+bwd' if train else 'fwd'} of the same P points (PyTorch-CPU restatement)",
+                                 "seconds_1_thread": round(d1, 3), "seconds_all_threads": round(dall, 3), "threads": threads_all}}
 
 
 if __name__ == "__main__":

@@ -70,8 +70,8 @@ int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
  *   so the caller need not clear them; with P == 0 the call returns at once and leaves them
  *   untouched (the reference's caller hands over zeros, rasterize_points.cu:68-70).
  * *num_rendered receives the number of (Gaussian, tile) instances.  One host
- * synchronisation on `stream` happens inside (to size the binning buffer), as in
- * rasterizer_impl.cu:282.
+ * wait on `stream` happens inside (to size the binning buffer), as in
+ * rasterizer_impl.cu:282; see gs4d_thread_state_release() below for how it is done.
  */
 int gs4d_rasterize_forward(
     gs4d_alloc_fn geom_alloc, void* geom_ctx,
@@ -101,8 +101,9 @@ int gs4d_rasterize_forward(
 /*
  * Backward.  Replaces Rasterizer::backward (rasterizer.h:56-87; rasterizer_impl.cu:343-444).
  * R is the num_rendered the forward returned; geom/binning/img buffers are the chunks the
- * forward filled.  All dL_d* outputs must be zero-initialised by the caller
- * (rasterize_points.cu:154-163): dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P],
+ * forward filled.  All dL_d* outputs except dL_dmean2D must be zero-initialised by the caller
+ * (rasterize_points.cu:154-163; dL_dmean2D is written in full whenever P > 0 and R > 0, otherwise the call
+ * returns at once and writes nothing): dL_dmean2D [P,3], dL_dconic [P,4], dL_dopacity [P],
  * dL_dcolor [P,3], dL_ddepth [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3],
  * dL_dscale [P,3], dL_drot [P,4].
  * `scratch_alloc` provides the per-instance gradient rows (48 bytes x R) that replace the
@@ -124,6 +125,20 @@ int gs4d_rasterize_backward(
     float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot,
     int debug,
     void* stream);
+
+/*
+ * Per-thread cached state of gs4d_rasterize_forward (no counterpart in the reference, whose forward pays a blocking
+ * cudaMemcpy instead, rasterizer_impl.cu:282): every calling thread lazily owns 64 bytes of pinned, coherent host
+ * memory -- the mailbox into which the scan kernel posts num_rendered -- plus the previous call's num_rendered, used
+ * to request the binning chunk before the count is known.  Nothing is shared between threads.  The host polls the
+ * mailbox for at most GS4D_MAILBOX_SPIN_US microseconds (environment, default 5000) and then falls back to
+ * hipMemcpyAsync + hipStreamSynchronize; GS4D_NO_MAILBOX=1 always takes that path.
+ * gs4d_thread_state_release() frees the calling thread's mailbox (call it before the thread exits or the library is
+ * unloaded; a later forward simply allocates a new one).  gs4d_mailbox_stats() reports how often the calling thread
+ * received the count through the mailbox (*fast) and through the copy + synchronise path (*slow).
+ */
+void gs4d_thread_state_release(void);
+void gs4d_mailbox_stats(unsigned long long* fast, unsigned long long* slow);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; rasterizer_impl.cu:54-66,141-153. `present` is device uint8/bool [P]. */
 int gs4d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -64,3 +64,26 @@ def test_plan_is_invalidated_by_new_storage_and_not_copied():
     assert "_step_cache" not in clone.__dict__
     net.float()                                                   # _apply drops the cache
     assert net.__dict__.get("_step_cache") is None
+
+
+def test_step_cache_is_dropped_by_set_aabb_and_extra_deform_switches():
+    """set_aabb installs a NEW aabb Parameter and the switches change the descriptor's flags; a plan cached
+    by an earlier forward_dynamic must not survive either (the GPU twin of this test checks the outputs change)."""
+    net = _net()
+    fake = lambda: (net._params(), {"plan": D._Plan(net._config(), net._params())}, net._flags(), net.grid.aabb)
+    net.__dict__["_step_cache"] = fake()
+    net.set_aabb([2.0, 2.0, 2.0], [-2.0, -2.0, -2.0])
+    assert net.__dict__.get("_step_cache") is None
+    net.__dict__["_step_cache"] = fake()
+    net.disable_extra_deform()
+    assert net.__dict__.get("_step_cache") is None and net._flags()[1:4] == (True, True, True)
+    net.__dict__["_step_cache"] = fake()
+    net.enable_extra_deform()
+    assert net.__dict__.get("_step_cache") is None and net._flags()[1:4] == (False, False, False)
+    # a direct assignment that bypasses the methods is caught by the per-step comparison of flags / aabb identity
+    cache = net.__dict__["_step_cache"] = fake()
+    net.args.no_ds = True
+    assert cache[2] != net._flags()
+    net.args.no_ds = False
+    net.grid.set_aabb([1.0, 1.0, 1.0], [-1.0, -1.0, -1.0])
+    assert net.grid.aabb is not cache[3]

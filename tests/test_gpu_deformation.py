@@ -129,3 +129,45 @@ def test_unsupported_configurations_fail_loudly():
     a.no_do = True
     with pytest.raises(RuntimeError, match="HIP device"):
         net.cpu().forward_dynamic(*(t.cpu() for t in (z(4, 3), z(4, 3), z(4, 4), z(4, 1), z(4, 16, 3), z(4, 1), z(4, 1))), None)
+
+
+def test_set_aabb_and_extra_deform_switches_take_effect_after_a_forward():
+    """the per-step plan cached by the first forward_dynamic must not outlive Deformation.set_aabb
+    (a NEW aabb Parameter) or enable_/disable_extra_deform (descriptor flags): compare with the oracle after each."""
+    from oracle import deformation_ref as R
+    cfg = R.DeformConfig(defor_depth=1, plane_channels=16, resolution=[16, 16, 16, 8], multires=[1, 2])
+    torch.manual_seed(11)
+    args = make_args(cfg)
+    net = pkg("scene.deformation").deform_network(args)
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "deform" in n and "bias" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    net = net.cuda()
+    P = 3000
+    g = torch.Generator().manual_seed(2)
+    ins = [torch.rand(P, 3, generator=g) * 2 - 1, torch.randn(P, 3, generator=g) * 0.5 - 3, torch.randn(P, 4, generator=g),
+           torch.randn(P, 1, generator=g), torch.randn(P, 16, 3, generator=g) * 0.3]
+    time, force = torch.full((P, 1), 0.37), torch.zeros(P, 1)
+
+    def both(cfg_now):
+        sd = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            want = R.forward_dynamic(sd, cfg_now, *ins, time, force)
+            got = net.forward_dynamic(*(t.cuda() for t in ins), time.cuda(), force.cuda(), None)
+        for n, a, b in zip(ORDER, got, want):
+            close(n, a, b, "fwd")
+        return [t.cpu() for t in got]
+
+    first = both(cfg)
+    net.deformation_net.set_aabb([2.5, 2.0, 1.5], [-1.5, -2.0, -2.5])          # after a forward has cached its plan
+    second = both(cfg)
+    assert float((first[0] - second[0]).abs().max()) > 1e-4                     # the new bounds really are in use
+    net.deformation_net.disable_extra_deform()
+    import dataclasses
+    third = both(dataclasses.replace(cfg, no_ds=True, no_dr=True, no_dshs=True))
+    assert torch.equal(third[1], ins[1]) and torch.equal(third[4], ins[4])      # scales / shs now pass through
+    net.deformation_net.enable_extra_deform()
+    fourth = both(cfg)
+    for a, b in zip(second, fourth):
+        assert torch.equal(a, b)

@@ -2,11 +2,14 @@
 libgs4d.so) against the CPU oracle on the same seeded inputs.
 
 Bars (BASELINE.json north_star): integer / indexing outputs bit-exact; colour, depth <= 1e-5 abs
-(depth relative to its magnitude); gradients <= 1e-4 relative to the tensor's max magnitude (3e-4 for the two chain-derived
-tensors dL_dscales / dL_drotations, see CHAIN_TOL).
+(depth relative to its magnitude); gradients <= 1e-4 where "relative" means: max |got - want| over the tensor divided
+by max |want| over the tensor (the definition every gradient check in this repository uses), for ALL eight tensors
+(round 1 held dL_dscales / dL_drotations to 3e-4; the per-Gaussian kernel now sums its instance rows in double).
 Pixels whose discrete blend decisions sit within 2e-5 (relative) of a threshold in the oracle
 are excluded from the float comparisons (exp() differs in the last ulp between libm and
-v_exp_f32; such a flip changes a pixel by up to alpha*T ~ 4e-3) and their count is bounded.
+v_exp_f32; such a flip changes a pixel by up to alpha*T ~ 4e-3) and their count is bounded.  Every check prints the
+excluded fraction, the largest error ON the excluded pixels and the achieved errors (pytest -rP / -s shows them);
+tests/test_gpu_exact_exp.py shows that the exclusion is only needed because of exp().
 """
 import numpy as np
 import pytest
@@ -61,6 +64,10 @@ def run_oracle(a, cam, deg, colors=None, cov=None, bg=(1, 1, 1), scale_modifier=
                      cam.image_height, cam.image_width, None if colors is not None else a["sh"], deg, cam.campos)
 
 
+LAST_FORWARD_REPORT = {}      # filled by check_forward: what was excluded and how large the error is on it
+LAST_GRADIENT_ERRORS = {}     # filled by grads_close: name -> achieved relative error
+
+
 def check_forward(a, cam, deg, **kw):
     R, color, depth, radii, gb, bb, ib = run_c(a, cam, deg, **kw)
     r = run_oracle(a, cam, deg, **kw)
@@ -88,11 +95,20 @@ def check_forward(a, cam, deg, **kw):
     eq("ranges", v["ranges"].cpu().numpy().view(np.uint32), r["ranges"])
     ok = r["margin"] > 2e-5
     assert ok.mean() > 0.995, ok.mean()
-    assert np.abs(color.cpu().numpy() - r["color"])[:, ok].max() <= 1e-5
+    cerr = np.abs(color.cpu().numpy() - r["color"])
+    nc = v["n_contrib"].cpu().numpy().view(np.uint32)
+    LAST_FORWARD_REPORT.clear()
+    LAST_FORWARD_REPORT.update(
+        P=P, W=W, H=H, excluded_fraction=float(1 - ok.mean()), colour_err_kept=float(cerr[:, ok].max()),
+        colour_err_excluded=float(cerr[:, ~ok].max()) if (~ok).any() else 0.0,
+        n_contrib_mismatch_excluded=int((nc[~ok] != r["n_contrib"][~ok]).sum()),
+        n_contrib_mismatch_all=int((nc != r["n_contrib"]).sum()))
+    print("forward parity:", LAST_FORWARD_REPORT)
+    assert cerr[:, ok].max() <= 1e-5
     dmax = max(1.0, float(r["depths"][vis].max()) if vis.any() else 1.0)
     assert np.abs(depth.cpu().numpy() - r["depth"])[:, ok].max() <= 1e-5 * dmax
     assert np.abs(v["final_T"].cpu().numpy() - r["final_T"])[ok].max() <= 1e-5
-    eq("n_contrib", v["n_contrib"].cpu().numpy().view(np.uint32)[ok], r["n_contrib"][ok])
+    eq("n_contrib", nc[ok], r["n_contrib"][ok])
     return r, (R, color, depth, radii, gb, bb, ib)
 
 
@@ -129,17 +145,19 @@ def test_duplicate_depths_keep_index_order():
     check_forward(a, cam, 3)
 
 
-# dL_dscales / dL_drotations are derived from dL_dcov3D through a cancelling chain; the float32
-# summation-order noise of the reference algorithm itself reaches ~1e-4 of their max there
-# (measured in tests/test_oracle_rasterizer.py::test_float32_summation_noise_floor...), so they get 3e-4.
-CHAIN_TOL = {"dL_dscales": 3e-4, "dL_drotations": 3e-4, "scales": 3e-4, "rotations": 3e-4}
+# dL_dscales / dL_drotations are derived from dL_dcov3D through a cancelling chain; with float32 accumulators the
+# reference algorithm's own summation-order noise reaches ~1e-4 of their max there
+# (tests/test_oracle_rasterizer.py::test_float32_accumulation_noise_floor).  The HIP path sums the per-tile partial
+# rows of a Gaussian in double (csrc/geom_bwd.hip), which brings these two tensors inside north_star's 1e-4 as well.
+GRAD_TOL = 1e-4
 
 
 def grads_close(name, got, want, tol=None):
-    tol = CHAIN_TOL.get(name, 1e-4) if tol is None else tol
+    tol = GRAD_TOL if tol is None else tol
     got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
     scale = max(np.abs(want).max(), 1e-20)
     err = np.abs(got - want).max() / scale
+    LAST_GRADIENT_ERRORS[name] = float(err)
     assert err <= tol, (name, err)
 
 
@@ -164,6 +182,7 @@ def check_backward(a, cam, deg, seed=0, depth_grad=0.1, **kw):
             dev(cam.viewmatrix), dev(cam.projmatrix), cam.tanfovx, cam.tanfovy, dev(gc), dev(gd),
             e if colors is not None else dev(a["sh"]), deg, dev(cam.campos), gb, R, bb, ib, False)
 
+    LAST_GRADIENT_ERRORS.clear()
     got = call()
     names = ["dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales", "dL_drotations"]
     for n, g in zip(names, got):
@@ -172,6 +191,7 @@ def check_backward(a, cam, deg, seed=0, depth_grad=0.1, **kw):
             assert g.numel() == 0
             continue
         grads_close(n, g.cpu().numpy().reshape(w.shape), w)
+    print("backward parity (max err / max |want|):", {k: f"{v:.2e}" for k, v in LAST_GRADIENT_ERRORS.items()})
     again = call()
     for n, g1, g2 in zip(names, got, again):  # no atomics anywhere: bitwise reproducible
         assert torch.equal(g1, g2), n
@@ -288,3 +308,45 @@ def test_outputs_do_not_depend_on_previous_buffer_contents():
              scales=dev(b["scales"]), rotations=dev(b["rotations"]))
     _dirty_allocator()
     check_forward(a, cam, 3)
+
+
+def test_outputs_are_independent_tensors_and_accept_in_place_ops():
+    """the reference returns separately allocated tensors; callers clamp the image in place
+    (image.clamp_(0, 1)) before the loss.  Views of one block made autograd refuse that."""
+    D = dgr()
+    a, cam = scene(400, 64, 48, 21, 0.08)
+    rast = D.GaussianRasterizer(settings(cam, 3))
+    t = {k: dev(a[k], True) for k in ("means3D", "opacities", "sh", "scales", "rotations")}
+    means2D = torch.zeros_like(t["means3D"], requires_grad=True)
+    color, radii, depth = rast(means3D=t["means3D"], means2D=means2D, opacities=t["opacities"], shs=t["sh"],
+                               scales=t["scales"], rotations=t["rotations"])
+    ptrs = {x.untyped_storage().data_ptr() for x in (color, radii, depth)}
+    assert len(ptrs) == 3 and all(x._base is None for x in (color, radii, depth))
+    color.clamp_(0.0, 1.0)
+    depth.mul_(2.0)
+    radii.clamp_(max=10)
+    (color.sum() + depth.sum()).backward()
+    assert means2D.grad is not None and means2D.grad._base is None      # does not pin the rasterizer's gradient block
+    assert float(means2D.grad[:, 2].abs().max()) == 0.0 and bool(torch.isfinite(means2D.grad).all())
+    assert float(means2D.grad[radii.cpu() == 0].abs().max() if (radii == 0).any() else 0.0) == 0.0
+    F = pkg("fused")
+    s, r, o = F.activate(t["scales"].detach().log().requires_grad_(True), t["rotations"], t["opacities"])
+    s.mul_(1.0); r.add_(0.0); o.clamp_(0, 1)                             # in-place on each output: must not raise
+    (s.sum() + r.sum() + o.sum()).backward()
+    loss = F.l1_loss(color.detach().requires_grad_(True), torch.zeros_like(color))
+    loss += 1.0                                                          # train.py accumulates regularisers in place
+    loss.backward()
+
+
+def test_nan_opacity_is_blended_like_the_reference():
+    """alpha = min(0.99, NaN * G) is 0.99 under fminf semantics (CUDA's min(float, float) and C's
+    fminf both return the non-NaN operand), `power > 0` and `alpha < 1/255` are false, so the reference BLENDS a
+    splat with a NaN opacity over every pixel of its tiles where power <= 0.  The alpha-support culling here must not
+    drop it silently (its box is "never cull"); compared with the oracle, which restates forward.cu:336-354."""
+    a, cam = scene(60, 96, 80, 31, 0.05)
+    a["opacities"][7] = np.nan
+    a["opacities"][23] = np.float32(1.0 / 255.0)          # exactly the threshold: visible only at the splat centre
+    r, out = check_forward(a, cam, 3)
+    touched = r["tiles_touched"][7]
+    assert touched > 0                                     # the NaN splat is on screen, so the case is exercised
+    assert np.isfinite(out[1].cpu().numpy()).all()         # 0.99, not NaN, reaches the image (as in the reference)

@@ -100,11 +100,12 @@ def ref_regulation(grids, tsw, l1w, l2w, ptw):
     return total
 
 
-def test_plane_regulation_matches_reference_expressions():
+@pytest.mark.parametrize("multires", [[1, 2], [1, 2, 4]])       # 24 terms in one call; 36 terms = two chunks
+def test_plane_regulation_matches_reference_expressions(multires):
     from test_gpu_deformation import make_args
     from oracle import deformation_ref as R
     reg = pkg("scene.regulation")
-    cfg = R.DeformConfig(plane_channels=16, resolution=[12, 10, 14, 9], multires=[1, 2])
+    cfg = R.DeformConfig(plane_channels=16, resolution=[12, 10, 14, 9], multires=multires)
     torch.manual_seed(5)
     net = pkg("scene.deformation").deform_network(make_args(cfg)).cuda()
     grids = net.deformation_net.grid.grids
@@ -115,7 +116,9 @@ def test_plane_regulation_matches_reference_expressions():
     assert abs(float(out["total_reg"].detach()) - float(want.detach())) <= 1e-5 * abs(float(want.detach()))
     parts = float(out["time_reg"]) + float(out["plane_reg"]) + float(out["l1_time_reg"]) + float(out["l2_time_reg"])
     assert abs(parts - float(want.detach())) <= 1e-5 * abs(float(want.detach()))
-    (out["total_reg"] * 3.0).backward()
+    loss = out["total_reg"] * 3.0
+    loss += 0.0                                      # callers accumulate in place (train.py `loss += tv_loss`): must not raise
+    loss.backward()
     (want * 3.0).backward()
     for lg, lc in zip(grids, cpu):
         for pg, pc in zip(lg, lc):
