@@ -13,6 +13,8 @@
 // LDS radix sort of the rasterizer.
 #include <float.h>
 
+#include <mutex>
+
 #include "gs4d_internal.h"
 
 #define KNN_BOX 1024
@@ -433,6 +435,50 @@ __global__ __launch_bounds__(256) void kq_query_kernel(int n, int m, int k, int 
 
 }  // namespace
 
+// scratch layout of the 3-NN pipeline, shared by the two entry points below
+namespace {
+struct KnnScratch {
+    float* partial; float* bbox; uint64_t* codes; uint32_t* ids; uint64_t* ktmp[2]; uint32_t* vtmp[2]; uint32_t* hist;
+    float4* sorted; Box* boxes; int nboxes, nred;
+};
+
+size_t knn_carve(char* base, int P, KnnScratch& k)
+{
+    k.nboxes = (P + KNN_BOX - 1) / KNN_BOX;
+    k.nred = min(1024, (P + 255) / 256);
+    char* p = base;
+    gs4d_obtain(p, k.partial, (size_t)k.nred * 6);
+    gs4d_obtain(p, k.bbox, 8);
+    gs4d_obtain(p, k.codes, (size_t)P);
+    gs4d_obtain(p, k.ids, (size_t)P);
+    gs4d_obtain(p, k.ktmp[0], (size_t)P);
+    gs4d_obtain(p, k.ktmp[1], (size_t)P);
+    gs4d_obtain(p, k.vtmp[0], (size_t)P);
+    gs4d_obtain(p, k.vtmp[1], (size_t)P);
+    gs4d_obtain(p, k.hist, (size_t)256 * gs4d_sort_blocks((size_t)P) + 256);
+    gs4d_obtain(p, k.sorted, (size_t)P);
+    gs4d_obtain(p, k.boxes, (size_t)k.nboxes);
+    return (size_t)(p - base) + 256;
+}
+
+// Every array of the scratch is written in full by a kernel before another kernel reads it (bbox partials, Morton
+// codes, the radix-sort histograms of each pass, sorted points, boxes): nothing has to start at zero.
+int knn_run(const KnnScratch& k, int P, const float* points, float* mean_dist2, hipStream_t s)
+{
+    hipLaunchKernelGGL(bbox_partial_kernel, dim3(k.nred), dim3(256), 0, s, P, points, k.partial);
+    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, s, k.nred, k.partial, k.bbox);
+    hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, k.bbox, k.codes, k.ids);
+    GS4D_LAUNCH_CHECK("knn_morton", 0, s);
+    int where = 0;
+    int rc = gs4d_radix_sort_pairs((uint32_t)P, 4, 0, k.codes, k.ids, k.ktmp, k.vtmp, k.hist, &where, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(gather_box_kernel, dim3(k.nboxes), dim3(KNN_BOX), 0, s, P, points, k.vtmp[where], k.sorted, k.boxes);
+    hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, k.nboxes, k.sorted, k.boxes, mean_dist2);
+    GS4D_LAUNCH_CHECK("knn_mean_dist", 0, s);
+    return GS4D_OK;
+}
+}  // namespace
+
 extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float* points,
                                    float* mean_dist2, void* stream)
 {
@@ -443,44 +489,67 @@ extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, 
         return GS4D_EINVAL;
     }
     GS4D_PROF("knn", s);
-    const int nboxes = (P + KNN_BOX - 1) / KNN_BOX;
-    const int nred = min(1024, (P + 255) / 256);
-    // carve scratch
-    char* p = nullptr;
-    float* partial; float* bbox; uint64_t* codes; uint32_t* ids; uint64_t* ktmp[2]; uint32_t* vtmp[2]; uint32_t* hist;
-    float4* sorted; Box* boxes;
-    auto carve = [&](char* base) {
-        p = base;
-        gs4d_obtain(p, partial, (size_t)nred * 6);
-        gs4d_obtain(p, bbox, 8);
-        gs4d_obtain(p, codes, (size_t)P);
-        gs4d_obtain(p, ids, (size_t)P);
-        gs4d_obtain(p, ktmp[0], (size_t)P);
-        gs4d_obtain(p, ktmp[1], (size_t)P);
-        gs4d_obtain(p, vtmp[0], (size_t)P);
-        gs4d_obtain(p, vtmp[1], (size_t)P);
-        gs4d_obtain(p, hist, (size_t)256 * gs4d_sort_blocks((size_t)P) + 256);
-        gs4d_obtain(p, sorted, (size_t)P);
-        gs4d_obtain(p, boxes, (size_t)nboxes);
-    };
-    carve(nullptr);
-    const size_t bytes = (size_t)p + 256;
+    KnnScratch k;
+    const size_t bytes = knn_carve(nullptr, P, k);
     char* base = (char*)alloc(alloc_ctx, bytes);
     if (!base) { gs4d_set_error("knn scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)base & 255) { gs4d_set_error("knn scratch must be 256-byte aligned"); return GS4D_EINVAL; }
-    carve(base);
+    knn_carve(base, P, k);
+    return knn_run(k, P, points, mean_dist2, s);
+}
 
-    hipLaunchKernelGGL(bbox_partial_kernel, dim3(nred), dim3(256), 0, s, P, points, partial);
-    hipLaunchKernelGGL(bbox_final_kernel, dim3(1), dim3(64), 0, s, nred, partial, bbox);
-    hipLaunchKernelGGL(morton_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, points, bbox, codes, ids);
-    GS4D_LAUNCH_CHECK("knn_morton", 0, s);
-    int where = 0;
-    int rc = gs4d_radix_sort_pairs((uint32_t)P, 4, 0, codes, ids, ktmp, vtmp, hist, &where, 0, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(gather_box_kernel, dim3(nboxes), dim3(KNN_BOX), 0, s, P, points, vtmp[where], sorted, boxes);
-    hipLaunchKernelGGL(mean_dist_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, nboxes, sorted, boxes, mean_dist2);
-    GS4D_LAUNCH_CHECK("knn_mean_dist", 0, s);
-    return GS4D_OK;
+// ---- the same computation with NO allocation anywhere (include/gs4d.h: gs4d_knn_mean_dist2_static) ----
+// The pipeline's scratch (Morton keys, sort ping-pong buffers and histograms, sorted points, boxes) lives in a
+// file-scope device array of fixed size.  In host code the array's NAME is only a stand-in: the device address is
+// asked for once per device with hipGetSymbolAddress (each GPU holds its own copy at its own address) and only that
+// pointer is handed to kernels.
+#define GS4D_KNN_STATIC_MAX_POINTS 262144
+#define GS4D_KNN_STATIC_BYTES (16u << 20)
+#define GS4D_KNN_MAX_DEVICES 64
+static __device__ __align__(256) unsigned char scratch[GS4D_KNN_STATIC_BYTES];
+namespace {
+std::mutex g_static_mu;
+char* g_static_ptr[GS4D_KNN_MAX_DEVICES] = {};
+}  // namespace
+
+extern "C" int gs4d_knn_static_max_points(void) { return GS4D_KNN_STATIC_MAX_POINTS; }
+
+extern "C" int gs4d_knn_mean_dist2_static(int P, const float* points, float* mean_dist2, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return GS4D_OK;
+    if (P < 0 || !points || !mean_dist2) {
+        gs4d_set_error("gs4d_knn_mean_dist2_static: bad arguments");
+        return GS4D_EINVAL;
+    }
+    if (P > GS4D_KNN_STATIC_MAX_POINTS) {
+        gs4d_set_error("gs4d_knn_mean_dist2_static: %d points exceed the static scratch's maximum of %d "
+                       "(use gs4d_knn_mean_dist2 with an allocator)", P, GS4D_KNN_STATIC_MAX_POINTS);
+        return GS4D_EINVAL;
+    }
+    int dev = -1;
+    GS4D_HIP_CHECK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= GS4D_KNN_MAX_DEVICES) { gs4d_set_error("gs4d_knn_mean_dist2_static: device %d out of range", dev); return GS4D_EINVAL; }
+    char* base = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_static_mu);
+        if (!g_static_ptr[dev]) {                       // first call on this device (it is the current one)
+            void* q = nullptr;
+            const hipError_t e = hipGetSymbolAddress(&q, HIP_SYMBOL(scratch));
+            if (e != hipSuccess || !q) {
+                gs4d_set_error("gs4d_knn_mean_dist2_static: hipGetSymbolAddress failed: %s", hipGetErrorString(e));
+                return GS4D_EHIP;
+            }
+            g_static_ptr[dev] = (char*)q;
+        }
+        base = g_static_ptr[dev];
+    }
+    KnnScratch k;
+    if (knn_carve(base, P, k) > GS4D_KNN_STATIC_BYTES) {      // cannot happen for P <= the stated maximum; checked all the same
+        gs4d_set_error("gs4d_knn_mean_dist2_static: scratch layout for %d points exceeds %u bytes", P, GS4D_KNN_STATIC_BYTES);
+        return GS4D_EINVAL;
+    }
+    return knn_run(k, P, points, mean_dist2, s);
 }
 
 extern "C" int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,

@@ -184,6 +184,22 @@ int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float
                         void* stream);
 
 /*
+ * gs4d_knn_mean_dist2 for callers that cannot allocate.  NO counterpart in the reference: it exists for callers that
+ * must not call hipMalloc (or any allocator) -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid allocation.  Same inputs, outputs and results (bit for bit) as gs4d_knn_mean_dist2, but the pipeline's scratch
+ * (Morton keys, sort ping-pong buffers and histograms, sorted points, boxes: 52 bytes per point) lives in a file-scope
+ * device array of 16 MiB inside the library, so at most gs4d_knn_static_max_points() = 262 144 points are accepted
+ * (more: GS4D_EINVAL with a clear message; the reference calls distCUDA2 with 2 000 points).  The call makes no
+ * hipMalloc / hipFree / allocator call; the caller still provides `points` and `mean_dist2`.  Every GPU the library
+ * runs on holds its own 16 MiB copy until the process ends; the array's device address is looked up once per device
+ * (hipGetSymbolAddress, on the first call with that device current).  All calls on one GPU share that array: calls that
+ * overlap on one GPU (different streams or threads) RACE -- serialise them.  Nothing in the scratch has to start at
+ * zero (every array is written in full before it is read), so stale contents of an earlier, larger call are harmless.
+ */
+int gs4d_knn_static_max_points(void);
+int gs4d_knn_mean_dist2_static(int P, const float* points, float* mean_dist2, void* stream);
+
+/*
  * k-nearest-neighbour query of the fork's rigidity regulariser.  Replaces
  * knnquery_cuda for ONE batch segment: pointops2/src/knnquery/knnquery_cuda_kernel.cu:65-108 (launcher :111-116,
  * Python KNNQuery pointops2/functions/pointops.py:34-49, caller utils/general_utils.py:144-158).
