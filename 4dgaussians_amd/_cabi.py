@@ -13,7 +13,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgs4d.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("GS4D_LIB_NAME", "libgs4d.so"))      # GS4D_LIB_NAME: kernel experiments only
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

@@ -27,6 +27,8 @@
 //  * plane gradients: points are binned by texel cell (counting sort), their adds combined in
 //    registers per cell, and only the combined rows go to memory with float atomics (the only
 //    non-deterministic sums in the library).
+#include <stdlib.h>
+
 #include "gs4d_internal.h"
 
 #define WIDTH 64            // net_width of every supported config
@@ -89,6 +91,7 @@ struct Workspace {
     float* Z;                      // [P][ldz]
     float* H1;                     // [P][256]
     float* O;                      // [P][64]
+    unsigned* hmask;               // [P][10] ReLU sign bits of H1 and of the hidden columns (fused heads, deform_heads.h)
 };
 
 static Workspace carve_workspace(char* base, const gs4d_deform_desc* d, const Layout& l, size_t P, size_t* bytes)
@@ -102,6 +105,7 @@ static Workspace carve_workspace(char* base, const gs4d_deform_desc* d, const La
     gs4d_obtain(p, w.Z, P * l.ldz);
     gs4d_obtain(p, w.H1, P * NHEAD * WIDTH);
     gs4d_obtain(p, w.O, P * OUT_LD);
+    gs4d_obtain(p, w.hmask, P * 10);
     if (bytes) *bytes = (size_t)(p - base) + 256;
     return w;
 }
@@ -650,7 +654,9 @@ __global__ __launch_bounds__(256) void pe_backward_kernel(PeArgs a, const float*
                                                           const float* __restrict__ scales,
                                                           const float* __restrict__ rots, const float* __restrict__ dZ,
                                                           float* __restrict__ dxyz, float* __restrict__ dscales,
-                                                          float* __restrict__ drots, int* __restrict__ clear, int nclear)
+                                                          float* __restrict__ drots, int* __restrict__ clear, int nclear,
+                                                          int apply_mask)    // 1: dZ is unmasked (fused heads): the ReLU mask of a
+                                                                             // column is the sign of its recomputed sine / cosine
 {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     // the cell histograms of the plane backward (next launch in the stream) start at zero: cleared here, by lanes this
@@ -670,8 +676,10 @@ __global__ __launch_bounds__(256) void pe_backward_kernel(PeArgs a, const float*
         const float fr = (float)(1 << k);
         float sn, cs;
         sincosf(x * fr, &sn, &cs);
-        acc += g[d * npe + k] * cs * fr;
-        acc -= g[dim * npe + d * npe + k] * sn * fr;
+        const float gs_ = (!apply_mask || sn > 0.f) ? g[d * npe + k] : 0.f;
+        const float gc_ = (!apply_mask || cs > 0.f) ? g[dim * npe + d * npe + k] : 0.f;
+        acc += gs_ * cs * fr;
+        acc -= gc_ * sn * fr;
     }
     dst[d] += acc;
 }
@@ -1275,6 +1283,112 @@ __global__ __launch_bounds__(256) void ft_embed_final_kernel(int nparts, const f
     if (threadIdx.x == 0) { d_w[0] += s[0][0]; d_w[1] += s[0][1]; d_b[0] += s[0][2]; }
 }
 
+#include "deform_heads.h"
+
+// ---- host side of the fused heads (deform_heads.h)
+static bool heads_layered_forced()
+{
+    static const bool v = [] { const char* e = getenv("GS4D_DEFORM_HEADS"); return e && e[0] == 'l'; }();   // "layered": round 1's path
+    return v;
+}
+
+static void heads_common(HeadsArgs& a, const gs4d_deform_desc* d, const Layout& l, int P)
+{
+    a = {};
+    a.P = P; a.ldz = l.ldz; a.nunits = (P + 31) / 32;
+    for (int h = 0; h < NHEAD; h++) {
+        a.W1[h] = d->head_w1[h]; a.b1[h] = d->head_b1[h]; a.W2[h] = d->head_w2[h]; a.b2[h] = d->head_b2[h];
+        a.in_w[h] = l.head_in[h];
+        a.seg_beg[h] = l.head_seg[h] < 0 ? 0 : l.head_seg[h];
+        a.seg_len[h] = l.head_seglen[h];
+        a.seg_blocks[h] = pad8(l.head_seglen[h]) / 8;
+    }
+    a.oT = l.oT; a.e = l.e; a.tf_blocks = pad8(l.e) / 8;
+    a.no_dx = d->no_dx; a.no_ds = d->no_ds; a.no_dr = d->no_dr; a.no_dshs = d->no_dshs; a.apply_rotation = d->apply_rotation;
+    a.pos_pe = d->pos_pe; a.sr_pe = d->sr_pe;
+}
+
+#define HEADS_LDS_LIMIT (160 * 1024 - 4096)      // dynamic LDS a fused-heads kernel may ask for (the backward also has a 2 KB static table)
+
+// forward layout (floats): W1 of the four heads | W2 pos, scales, rotations (512 each) | W2 shs (3072) | b1 (256) | b2 (112)
+static size_t heads_forward_layout(HeadsArgs& a)
+{
+    int off = 0;
+    for (int h = 0; h < NHEAD; h++) { a.w1_off[h] = off; off += (8 + a.seg_blocks[h] + a.tf_blocks) * 8 * WIDTH; }
+    for (int h = 0; h < 3; h++) { a.w2_off[h] = off; off += 8 * 2 * 8 * 4; }
+    a.w2_off[3] = off; off += 8 * 2 * 48 * 4;
+    a.b1_off = off; off += NHEAD * WIDTH;
+    a.b2_off = off; off += 64 + 48;
+    return (size_t)off * sizeof(float);
+}
+
+// backward layout (floats): W2^T of the four heads (1, 1, 1, 6 output blocks of 512) | W1^T hidden parts (4 x 4096) |
+// W1^T segment parts: pos (64 rows), scales (32 rows), rotations (32 rows)
+static size_t heads_backward_layout(HeadsArgs& a)
+{
+    int off = 0;
+    for (int h = 0; h < NHEAD; h++) { a.w2_off[h] = off; off += (h == 3 ? 6 : 1) * 8 * WIDTH; }
+    for (int h = 0; h < NHEAD; h++) { a.w1_off[h] = off; off += WIDTH * WIDTH; }
+    a.seg_off[0] = off; off += WIDTH * 64;
+    a.seg_off[1] = off; off += WIDTH * 32;
+    a.seg_off[2] = off; off += WIDTH * 32;
+    return (size_t)off * sizeof(float);
+}
+
+static bool heads_fused_ok(const gs4d_deform_desc* d, const Layout& l)
+{
+    if (heads_layered_forced()) return false;
+    HeadsArgs a;
+    heads_common(a, d, l, 1);
+    for (int h = 0; h < NHEAD; h++)
+        if (a.seg_blocks[h] > HF_MAX_SEG_BLOCKS) return false;
+    if (a.tf_blocks > HF_MAX_TF_BLOCKS) return false;
+    if (a.seg_len[1] > 32 || a.seg_len[2] > 32) return false;      // backward: one 32-row tile per small segment
+    return heads_forward_layout(a) <= HEADS_LDS_LIMIT && heads_backward_layout(a) <= HEADS_LDS_LIMIT;
+}
+
+static int heads_debug_units(int nunits)
+{
+    static const int v = [] { const char* e = getenv("GS4D_HF_DEBUG_UNITS"); return e ? atoi(e) : -1; }();   // experiments only
+    return v >= 0 && v < nunits ? v : nunits;
+}
+
+static int heads_grid(int nunits)
+{
+    // one persistent workgroup per CU (its weights fill most of the LDS); never more workgroups than units
+    return nunits < GEMM_CUS ? nunits : GEMM_CUS;
+}
+
+static int launch_heads_forward(HeadsArgs& a, hipStream_t s)
+{
+    const size_t lds = heads_forward_layout(a);
+    static size_t attr = 0;                      // the largest dynamic LDS size announced so far
+    if (lds > attr) {
+        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)heads_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const int grid = heads_grid(a.nunits);
+    a.nunits = heads_debug_units(a.nunits);
+    hipLaunchKernelGGL(heads_forward_kernel, dim3(grid), dim3(HF_THREADS), lds, s, a);
+    GS4D_LAUNCH_CHECK("deform_heads_forward", 0, s);
+    return GS4D_OK;
+}
+
+static int launch_heads_backward(HeadsArgs& a, hipStream_t s)
+{
+    const size_t lds = heads_backward_layout(a);
+    static size_t attr = 0;
+    if (lds > attr) {
+        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)heads_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = lds;
+    }
+    const int grid = heads_grid(a.nunits);
+    a.nunits = heads_debug_units(a.nunits);
+    hipLaunchKernelGGL(heads_backward_kernel, dim3(grid), dim3(HF_THREADS), lds, s, a);
+    GS4D_LAUNCH_CHECK("deform_heads_backward", 0, s);
+    return GS4D_OK;
+}
+
 // counting-sort geometry of the binned plane backward (see HexBins)
 static HexBins hex_bins(const gs4d_deform_desc* d)
 {
@@ -1485,6 +1599,15 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
         rc = launch_gemm(P, jobs, 1, s);
         if (rc) return rc;
     }
+    if (heads_fused_ok(d, l)) {
+        // all four heads, both Linears and the residual / quaternion outputs in ONE pass over the points (deform_heads.h)
+        HeadsArgs ha;
+        heads_common(ha, d, l, P);
+        ha.Z = w.Z; ha.H1 = w.H1; ha.O = w.O; ha.hmask = w.hmask; ha.store = d->no_grad ? 0 : 1;
+        ha.xyz = points; ha.scales = scales; ha.rots = rotations; ha.shs = shs;
+        ha.o_xyz = out_means3D; ha.o_scales = out_scales; ha.o_rots = out_rotations; ha.o_shs = out_shs;
+        return launch_heads_forward(ha, s);
+    }
     // heads, both Linears in one pass: H1_h = relu([hidden | pe_h | tf]) W1_h^T + b1_h (stored only when a backward
     // will read it), O[:, ocol_h ..] = relu(H1_h) W2_h^T + b2_h
     {
@@ -1552,7 +1675,21 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
     Gs4dProfScope* mlp_scope = do_data ? new Gs4dProfScope("mlp_backward", s) : nullptr;
     struct ScopeGuard { Gs4dProfScope*& p; ~ScopeGuard() { delete p; } } mlp_guard{mlp_scope};
     OutArgs oa = {P, d->no_dx, d->no_ds, d->no_dr, d->no_dshs, d->apply_rotation};
-    if (do_data) {
+    const bool fused_heads = heads_fused_ok(d, l);
+    if (do_data && fused_heads) {
+        // outputs backward, dH1, dZ (hidden columns) and the PE segments' input gradients in ONE pass (deform_heads.h);
+        // it also clears the plane backward's cell histograms
+        HeadsArgs ha;
+        heads_common(ha, d, l, P);
+        ha.Z = w.Z; ha.H1 = w.H1; ha.O = w.O; ha.hmask = w.hmask;
+        ha.xyz = points; ha.scales = scales; ha.rots = rotations;
+        ha.g_xyz = dL_dmeans3D; ha.g_scales = dL_dscales; ha.g_rots = dL_drotations; ha.g_shs = dL_dshs;
+        ha.dO = dO; ha.dH1 = dH1; ha.dZ = dZ;
+        ha.dxyz = dL_dpoints; ha.dscales = dL_dscales_in; ha.drots = dL_drotations_in; ha.dshs = dL_dshs_in;
+        rc = launch_heads_backward(ha, s);
+        if (rc) return rc;
+    }
+    if (do_data && !fused_heads) {
         hipLaunchKernelGGL(outputs_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, oa, w.O, rotations,
                            dL_dmeans3D, dL_dscales, dL_drotations, dL_dshs, dO, dL_dpoints, dL_dscales_in,
                            dL_drotations_in, dL_dshs_in);
@@ -1560,7 +1697,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
     }
 
     // dH1_h = (dO_h W2_h) * (H1_h > 0)
-    if (do_data) {
+    if (do_data && !fused_heads) {
         GemmJobs jobs = {};
         for (int h = 0; h < NHEAD; h++) {
             GemmJob& j = jobs.j[h];
@@ -1572,7 +1709,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         if (rc) return rc;
     }
     // dZ = (sum_h dH1_h W1_h scattered to Z columns) * (Z > 0): the hidden columns and the three PE segments
-    if (do_data) {
+    if (do_data && !fused_heads) {
         GemmJobs jobs = {};
         int nj = 0;
         auto all_heads = [&](int zcol0, int ncols, int wcol_of_head[NHEAD]) {
@@ -1651,6 +1788,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         add_dw(a);
         DwJob b = {};
         b.G = dO; b.ldg = OUT_LD; b.gcol0 = l.head_ocol[h]; b.N = l.head_out[h];
+        if (h == 3 && fused_heads && !d->no_dshs) { b.G = dL_dshs; b.ldg = 48; b.gcol0 = 0; }   // dO's SH columns ARE the upstream gradient: not copied
         b.X = w.H1; b.ldx = NHEAD * WIDTH; b.x_nseg = 1; b.x_beg[0] = h * WIDTH; b.x_len[0] = WIDTH; b.K = WIDTH;
         b.relu_x = 1; b.Kp = WIDTH; b.kblocks = (WIDTH + 1 + 31) / 32;
         b.slabs = slabs + slab_per_job * (NHEAD + h); b.dW = g->head_w2[h]; b.db = g->head_b2[h];
@@ -1663,7 +1801,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         const size_t threads = (size_t)P * 10;
         hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pa, points,
                            scales, rotations, dZ, dL_dpoints, dL_dscales_in, dL_drotations_in, hist,
-                           d->L * HEX_SORTS * hex_bins(d).nbins);
+                           d->L * HEX_SORTS * hex_bins(d).nbins, fused_heads ? 1 : 0);
         GS4D_LAUNCH_CHECK("pe_backward", 0, s);
     }
     delete mlp_scope;

@@ -227,7 +227,8 @@ class _DeformFunction(torch.autograd.Function):
             g_rot = g_rot.clone()
         if g_shs.data_ptr() % 16:
             g_shs = g_shs.clone()
-        d_xyz, d_sc, d_rot, d_shs = (torch.empty_like(t) for t in (points_, scales_, rot_, g_shs))
+        d_xyz, d_sc, d_rot = (torch.empty_like(t) for t in (points_, scales_, rot_))
+        d_shs = g_shs            # shs' = shs + delta: the input gradient IS the upstream gradient (the C ABI allows the alias)
         scratch = torch.empty(max(int(L.gs4d_deform_backward_scratch_bytes(C.byref(d), C.c_int(P))), 256),
                               dtype=torch.uint8, device=dev)
         hook = cfg.get("data_grad_hook")

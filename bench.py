@@ -345,7 +345,8 @@ def main():
                        "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
                        "log_s0_offset": round(log_s0_offset, 4),
                        "grad_allreduce_bytes": bucket.nbytes, "collectives": collectives if dp else None,
-                       "collectives_fallback": collectives_fallback},
+                       "collectives_fallback": collectives_fallback,
+                       "num_rendered_wait": dict(zip(("mailbox", "copy_sync_fallback"), cabi.mailbox_stats()))},
             "roofline": roofline, "cpu_baseline": cpu, "render_fps": render_fps,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
