@@ -1369,7 +1369,7 @@ static int launch_heads_forward(HeadsArgs& a, hipStream_t s)
     }
     const int grid = heads_grid(a.nunits);
     a.nunits = heads_debug_units(a.nunits);
-    hipLaunchKernelGGL(heads_forward_kernel, dim3(grid), dim3(HF_THREADS), lds, s, a);
+    hipLaunchKernelGGL(heads_forward_kernel, dim3(grid), dim3(HFF_THREADS), lds, s, a);
     GS4D_LAUNCH_CHECK("deform_heads_forward", 0, s);
     return GS4D_OK;
 }

@@ -21,6 +21,7 @@
 #pragma once
 
 #define HF_THREADS 512
+#define HFF_THREADS 768          // forward: 152 VGPRs -> three waves per SIMD
 #define HF_WAVES (HF_THREADS / 64)
 #define HF_MAX_SEG_BLOCKS 8
 #define HF_MAX_TF_BLOCKS 4
@@ -104,23 +105,26 @@ __device__ __forceinline__ int hf_true_col(const HeadsArgs& a, int hd, int kp)
 // ------------------------------------------------------------------ forward
 // LDS: W1 of every head as [Kp_h / 8][2][64][4] | W2 of pos / scales / rotations as [8][2][8][4] | W2 of shs as
 // [8][2][48][4] | b1 [4][64] | b2 [64] (pos 0..2, scales 8..10, rotations 16..19, shs at OC_SH: the columns of O)
-__global__ __launch_bounds__(HF_THREADS) void heads_forward_kernel(HeadsArgs a)
+__global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
 {
     extern __shared__ float smem[];
+    __shared__ int s_next_item;
+    int* s_next = &s_next_item;
     const int tid = threadIdx.x;
+    if (tid == 0) s_next_item = 0;
     // zero the W1 region (padding columns), then every thread fetches its share of a head's weights in ONE batch of
     // loads before the first LDS store: staging costs a few memory round trips, not one per element
     {
         const int total4 = (a.w1_off[NHEAD - 1] + (8 + a.seg_blocks[NHEAD - 1] + a.tf_blocks) * 8 * WIDTH) >> 2;
         float4* z4 = reinterpret_cast<float4*>(smem);
-        for (int e = tid; e < total4; e += HF_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int e = tid; e < total4; e += HFF_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
     for (int hd = 0; hd < NHEAD; hd++) {
         float* dst = smem + a.w1_off[hd];
         const float* __restrict__ W = a.W1[hd];
         const int ld = a.in_w[hd];
-        const int j = tid >> 3, c0 = tid & 7;                  // row (H1 unit) and first column of this thread
+        const int j = min(tid >> 3, WIDTH - 1), c0 = tid & 7;  // row (H1 unit) and first column of this thread (threads >= 512 idle here)
         const int tf0 = WIDTH + a.seg_len[hd], tfp = WIDTH + a.seg_blocks[hd] * 8;   // first tf column: true / padded
         float v[(WIDTH + HF_MAX_SEG_BLOCKS * 8 + HF_MAX_TF_BLOCKS * 8) / 8];
 #pragma unroll
@@ -131,36 +135,48 @@ __global__ __launch_bounds__(HF_THREADS) void heads_forward_kernel(HeadsArgs a)
 #pragma unroll
         for (int it = 0; it < (int)(sizeof(v) / sizeof(float)); it++) {
             const int c = c0 + 8 * it;
-            if (c < ld) dst[hf_slot(c < tf0 ? c : c - tf0 + tfp, j, WIDTH)] = v[it];
+            if (c < ld && tid < 8 * WIDTH) dst[hf_slot(c < tf0 ? c : c - tf0 + tfp, j, WIDTH)] = v[it];
         }
         const int rows = hd == 3 ? 48 : 8, nout = hd == 3 ? 48 : (hd == 2 ? 4 : 3);
         float* d2 = smem + a.w2_off[hd];
         const float* __restrict__ W2 = a.W2[hd];
-        for (int e = tid; e < rows * WIDTH; e += HF_THREADS) {
+        for (int e = tid; e < rows * WIDTH; e += HFF_THREADS) {
             const int j = e >> 6, k = e & 63;
             d2[hf_slot(k, j, rows)] = j < nout ? W2[(size_t)j * WIDTH + k] : 0.f;
         }
-        for (int e = tid; e < WIDTH; e += HF_THREADS) smem[a.b1_off + hd * WIDTH + e] = a.b1[hd][e];
+        for (int e = tid; e < WIDTH; e += HFF_THREADS) smem[a.b1_off + hd * WIDTH + e] = a.b1[hd][e];
     }
-    for (int e = tid; e < 64; e += HF_THREADS) {
+    for (int e = tid; e < 64; e += HFF_THREADS) {
         float v = 0.f;
         if (e < 3) v = a.b2[0][e];
         else if (e >= OC_S && e < OC_S + 3) v = a.b2[1][e - OC_S];
         else if (e >= OC_R && e < OC_R + 4) v = a.b2[2][e - OC_R];
         smem[a.b2_off + e] = v;
     }
-    for (int e = tid; e < 48; e += HF_THREADS) smem[a.b2_off + 64 + e] = a.b2[3][e];
+    for (int e = tid; e < 48; e += HFF_THREADS) smem[a.b2_off + 64 + e] = a.b2[3][e];
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6, i = lane & 31, h = lane >> 5;
+    const int lane = tid & 63, i = lane & 31, h = lane >> 5;
     const float4* sb1 = reinterpret_cast<const float4*>(smem + a.b1_off);
     const float* sb2 = smem + a.b2_off;
-    for (int u = blockIdx.x + gridDim.x * wave; u < a.nunits; u += gridDim.x * HF_WAVES) {
+    // Work items are (32-point unit, head) pairs handed out dynamically inside the workgroup: whole units quantise
+    // badly (3125 units on 1024 SIMDs at C2: 3 or 4 each), a quarter of a unit does not.  The workgroup owns units
+    // blockIdx.x, blockIdx.x + gridDim.x, ...; the hidden / embedding columns are re-read per item (L1 / L2 hits).
+    const int my_units = a.nunits > (int)blockIdx.x ? (a.nunits - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    const int nitems = my_units * NHEAD;
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(s_next, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= nitems) break;
+        const int u = (int)blockIdx.x + (int)gridDim.x * (item >> 2);
+        const int hd = item & 3;
         const int prow = u * 32 + i;
         const bool live = prow < a.P;
         const size_t row = (size_t)min(prow, a.P - 1);
         const float* __restrict__ z = a.Z + row * a.ldz + 4 * h;
-        float4 xh[8], xt[HF_MAX_TF_BLOCKS];
+        float4 xh[8], xt[HF_MAX_TF_BLOCKS], xs[HF_MAX_SEG_BLOCKS];
+        const int nseg = a.seg_blocks[hd];
         unsigned hid_bits = 0u;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
@@ -168,110 +184,106 @@ __global__ __launch_bounds__(HF_THREADS) void heads_forward_kernel(HeadsArgs a)
             hid_bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
             xh[m] = hf_relu4(v);
         }
-        if (a.store && live) a.hmask[row * 10 + 8 + h] = hid_bits;
+#pragma unroll
+        for (int m = 0; m < HF_MAX_SEG_BLOCKS; m++)
+            if (m < nseg) xs[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.seg_beg[hd] + 8 * m));
 #pragma unroll
         for (int m = 0; m < HF_MAX_TF_BLOCKS; m++)
-            xt[m] = m < a.tf_blocks ? hf_relu4(*reinterpret_cast<const float4*>(z + a.oT + 8 * m)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < a.tf_blocks) xt[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.oT + 8 * m));
+        if (hd == 0 && a.store && live) a.hmask[row * 10 + 8 + h] = hid_bits;
+
+        f32x16 c0 = {0}, c1 = {0};
+        const float4* w = reinterpret_cast<const float4*>(smem + a.w1_off[hd]) + h * 64 + i;
 #pragma unroll
-        for (int hd = 0; hd < NHEAD; hd++) {
-            const int nseg = a.seg_blocks[hd];
-            float4 xs[HF_MAX_SEG_BLOCKS];
+        for (int m = 0; m < 8; m++) hf_mm2(c0, c1, w[m * 128], w[m * 128 + 32], xh[m]);
+        w += 8 * 128;
 #pragma unroll
-            for (int m = 0; m < HF_MAX_SEG_BLOCKS; m++)
-                if (m < nseg) xs[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.seg_beg[hd] + 8 * m));
-            f32x16 c0 = {0}, c1 = {0};
-            const float4* w = reinterpret_cast<const float4*>(smem + a.w1_off[hd]) + h * 64 + i;
+        for (int m = 0; m < HF_MAX_SEG_BLOCKS; m++)
+            if (m < nseg) hf_mm2(c0, c1, w[m * 128], w[m * 128 + 32], xs[m]);
+        w += nseg * 128;
 #pragma unroll
-            for (int m = 0; m < 8; m++) hf_mm2(c0, c1, w[m * 128], w[m * 128 + 32], xh[m]);
-            w += 8 * 128;
+        for (int m = 0; m < HF_MAX_TF_BLOCKS; m++)
+            if (m < a.tf_blocks) hf_mm2(c0, c1, w[m * 128], w[m * 128 + 32], xt[m]);
+        // bias, optional store of the pre-activation (the weight-gradient operand) and of its sign bits, ReLU
+        float4 xr[8];
+        float* __restrict__ h1row = a.H1 + row * (NHEAD * WIDTH) + hd * WIDTH + 4 * h;
+        unsigned bits = 0u;
 #pragma unroll
-            for (int m = 0; m < HF_MAX_SEG_BLOCKS; m++)
-                if (m < nseg) hf_mm2(c0, c1, w[m * 128], w[m * 128 + 32], xs[m]);
-            w += nseg * 128;
-#pragma unroll
-            for (int m = 0; m < HF_MAX_TF_BLOCKS; m++)
-                if (m < a.tf_blocks) hf_mm2(c0, c1, w[m * 128], w[m * 128 + 32], xt[m]);
-            // bias, optional store of the pre-activation (the backward's ReLU mask and weight-gradient operand), ReLU
-            float4 xr[8];
-            float* __restrict__ h1row = a.H1 + row * (NHEAD * WIDTH) + hd * WIDTH + 4 * h;
-            unsigned bits = 0u;
+        for (int m = 0; m < 8; m++) {
+            const float4 b = sb1[hd * 16 + 2 * m + h];
+            const float4 q = hf_quad(m < 4 ? c0 : c1, m & 3);
+            const float4 v = make_float4(q.x + b.x, q.y + b.y, q.z + b.z, q.w + b.w);
+            if (a.store && live) *reinterpret_cast<float4*>(h1row + 8 * m) = v;
+            bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
+            xr[m] = hf_relu4(v);
+        }
+        if (a.store && live) a.hmask[row * 10 + 2 * hd + h] = bits;   // the backward's ReLU mask: 4 bytes instead of 128
+        if (hd < 3) {
+            f32x16 o = {0};
+            const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[hd]) + h * 8 + (i & 7);
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                const float4 b = sb1[hd * 16 + 2 * m + h];
-                const float4 q = hf_quad(m < 4 ? c0 : c1, m & 3);
-                const float4 v = make_float4(q.x + b.x, q.y + b.y, q.z + b.z, q.w + b.w);
-                if (a.store && live) *reinterpret_cast<float4*>(h1row + 8 * m) = v;
-                bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
-                xr[m] = hf_relu4(v);
+                float4 wv = w2[m * 16];
+                if (i >= 8) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+                hf_mm1(o, wv, xr[m]);
             }
-            if (a.store && live) a.hmask[row * 10 + 2 * hd + h] = bits;   // the backward's ReLU mask: 4 bytes instead of 128
-            if (hd < 3) {
-                f32x16 o = {0};
-                const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[hd]) + h * 8 + (i & 7);
+            if (h == 0 && live) {       // features 0..3 of the point sit in registers 0..3 of the h = 0 lane
+                if (hd == 0) {
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    float4 wv = w2[m * 16];
-                    if (i >= 8) wv = make_float4(0.f, 0.f, 0.f, 0.f);
-                    hf_mm1(o, wv, xr[m]);
-                }
-                if (h == 0 && live) {       // features 0..3 of the point sit in registers 0..3 of the h = 0 lane
-                    if (hd == 0) {
+                    for (int c = 0; c < 3; c++) {
+                        const float x = a.xyz[3 * row + c];
+                        a.o_xyz[3 * row + c] = a.no_dx ? x : x + (o[c] + sb2[OC_X + c]);
+                    }
+                } else if (hd == 1) {
 #pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            const float x = a.xyz[3 * row + c];
-                            a.o_xyz[3 * row + c] = a.no_dx ? x : x + (o[c] + sb2[OC_X + c]);
-                        }
-                    } else if (hd == 1) {
-#pragma unroll
-                        for (int c = 0; c < 3; c++) {
-                            const float x = a.scales[3 * row + c];
-                            a.o_scales[3 * row + c] = a.no_ds ? x : x + (o[c] + sb2[OC_S + c]);
-                        }
+                    for (int c = 0; c < 3; c++) {
+                        const float x = a.scales[3 * row + c];
+                        a.o_scales[3 * row + c] = a.no_ds ? x : x + (o[c] + sb2[OC_S + c]);
+                    }
+                } else {
+                    const float4 q1 = reinterpret_cast<const float4*>(a.rots)[row];
+                    const float4 q2 = make_float4(o[0] + sb2[OC_R], o[1] + sb2[OC_R + 1], o[2] + sb2[OC_R + 2], o[3] + sb2[OC_R + 3]);
+                    if (a.store) *reinterpret_cast<float4*>(a.O + row * OUT_LD + OC_R) = q2;
+                    float4 r;
+                    if (a.no_dr) {
+                        r = q1;
+                    } else if (!a.apply_rotation) {
+                        r = make_float4(q1.x + q2.x, q1.y + q2.y, q1.z + q2.z, q1.w + q2.w);
                     } else {
-                        const float4 q1 = reinterpret_cast<const float4*>(a.rots)[row];
-                        const float4 q2 = make_float4(o[0] + sb2[OC_R], o[1] + sb2[OC_R + 1], o[2] + sb2[OC_R + 2], o[3] + sb2[OC_R + 3]);
-                        if (a.store) *reinterpret_cast<float4*>(a.O + row * OUT_LD + OC_R) = q2;
-                        float4 r;
-                        if (a.no_dr) {
-                            r = q1;
-                        } else if (!a.apply_rotation) {
-                            r = make_float4(q1.x + q2.x, q1.y + q2.y, q1.z + q2.z, q1.w + q2.w);
-                        } else {
-                            float q[4];
-                            q[0] = q1.x * q2.x - q1.y * q2.y - q1.z * q2.z - q1.w * q2.w;
-                            q[1] = q1.x * q2.y + q1.y * q2.x + q1.z * q2.w - q1.w * q2.z;
-                            q[2] = q1.x * q2.z - q1.y * q2.w + q1.z * q2.x + q1.w * q2.y;
-                            q[3] = q1.x * q2.w + q1.y * q2.z - q1.z * q2.y + q1.w * q2.x;
-                            const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
-                            r = make_float4(q[0] / nrm, q[1] / nrm, q[2] / nrm, q[3] / nrm);
-                        }
-                        reinterpret_cast<float4*>(a.o_rots)[row] = r;
+                        float q[4];
+                        q[0] = q1.x * q2.x - q1.y * q2.y - q1.z * q2.z - q1.w * q2.w;
+                        q[1] = q1.x * q2.y + q1.y * q2.x + q1.z * q2.w - q1.w * q2.z;
+                        q[2] = q1.x * q2.z - q1.y * q2.w + q1.z * q2.x + q1.w * q2.y;
+                        q[3] = q1.x * q2.w + q1.y * q2.z - q1.z * q2.y + q1.w * q2.x;
+                        const float nrm = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+                        r = make_float4(q[0] / nrm, q[1] / nrm, q[2] / nrm, q[3] / nrm);
                     }
+                    reinterpret_cast<float4*>(a.o_rots)[row] = r;
                 }
-            } else {
-                f32x16 o0 = {0}, o1 = {0};
-                const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[3]) + h * 48;
+            }
+        } else {
+            f32x16 o0 = {0}, o1 = {0};
+            const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[3]) + h * 48;
 #pragma unroll
-                for (int m = 0; m < 8; m++) {
-                    const float4 wa = w2[m * 96 + i];
-                    float4 wb = w2[m * 96 + 32 + (i & 15)];
-                    if (i >= 16) wb = make_float4(0.f, 0.f, 0.f, 0.f);
-                    hf_mm2(o0, o1, wa, wb, xr[m]);
-                }
-                if (live) {
-                    const float4* __restrict__ sin4 = reinterpret_cast<const float4*>(a.shs + 48 * row + 4 * h);
-                    float4* __restrict__ sout4 = reinterpret_cast<float4*>(a.o_shs + 48 * row + 4 * h);
-                    const float4* b4 = reinterpret_cast<const float4*>(sb2 + 64) + h;
+            for (int m = 0; m < 8; m++) {
+                const float4 wa = w2[m * 96 + i];
+                float4 wb = w2[m * 96 + 32 + (i & 15)];
+                if (i >= 16) wb = make_float4(0.f, 0.f, 0.f, 0.f);
+                hf_mm2(o0, o1, wa, wb, xr[m]);
+            }
+            if (live) {
+                const float4* __restrict__ sin4 = reinterpret_cast<const float4*>(a.shs + 48 * row + 4 * h);
+                float4* __restrict__ sout4 = reinterpret_cast<float4*>(a.o_shs + 48 * row + 4 * h);
+                const float4* b4 = reinterpret_cast<const float4*>(sb2 + 64) + h;
 #pragma unroll
-                    for (int m = 0; m < 6; m++) {
-                        float4 s = sin4[2 * m];
-                        if (!a.no_dshs) {
-                            const float4 q = hf_quad(m < 4 ? o0 : o1, m & 3);
-                            const float4 b = b4[2 * m];
-                            s.x += q.x + b.x; s.y += q.y + b.y; s.z += q.z + b.z; s.w += q.w + b.w;
-                        }
-                        sout4[2 * m] = s;
+                for (int m = 0; m < 6; m++) {
+                    float4 s = sin4[2 * m];
+                    if (!a.no_dshs) {
+                        const float4 q = hf_quad(m < 4 ? o0 : o1, m & 3);
+                        const float4 b = b4[2 * m];
+                        s.x += q.x + b.x; s.y += q.y + b.y; s.z += q.z + b.z; s.w += q.w + b.w;
                     }
+                    sout4[2 * m] = s;
                 }
             }
         }
