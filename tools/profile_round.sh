@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 rm -rf "$out"; mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o r01 --output-format csv -- python3 "$root/bench.py" --steps 30 --warmup 5 --no-cpu-baseline > "$out/stats.log" 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/stats" -o r02 --output-format csv -- python3 "$root/bench.py" --steps 30 --warmup 5 --no-cpu-baseline > "$out/stats.log" 2>&1
 cp "$(find $out/stats -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 cd "$root"
 run_pmc() {
