@@ -5,6 +5,7 @@ only touches `param_groups` and `state`, which FusedAdamW shares with it)."""
 import types
 
 import numpy as np
+import pytest
 import torch
 
 from conftest import pkg
@@ -173,3 +174,54 @@ def test_capture_restore_and_deformation_files(tmp_path):
     assert torch.equal(m3._deformation_accum, m._deformation_accum)
     for (k, a), (_, b) in zip(m._deformation.state_dict().items(), m3._deformation.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+def test_ply_known_answer_bytes(tmp_path):
+    """Byte-level known-answer test of the PLY writer / reader.  PARITY UNPINNED against a
+    reference-written file: the reference ships no .ply and `plyfile` (its writer, scene/gaussian_model.py:290-295) is
+    not importable here.  The expected bytes below are written out by hand from the PLY 1.0 format as plyfile emits it
+    for PlyData([PlyElement.describe(structured_array_of_f4, 'vertex')]): text header with one `property float <name>`
+    line per field ('f4' -> "float"), `end_header\\n`, then the records as packed little-endian float32."""
+    import struct
+    names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "opacity"]
+    rows = [[1.0, -2.5, 3.25, 0.0, 0.0, 0.0, 0.5, -4.0], [1e-3, 2e10, -0.0, 0.0, 0.0, 0.0, float("inf"), 7.0]]
+    want = (b"ply\nformat binary_little_endian 1.0\nelement vertex 2\n"
+            b"property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+            b"property float f_dc_0\nproperty float opacity\nend_header\n")
+    want += b"".join(struct.pack("<8f", *r) for r in rows)
+    # spot values spelled out as hex: 1.0 = 3f800000, -2.5 = c0200000, 3.25 = 40500000 (little endian on disk)
+    assert want[want.index(b"end_header\n") + 11:][:12] == bytes.fromhex("0000803f" "000020c0" "00005040")
+    path = str(tmp_path / "kat.ply")
+    GM.write_ply(path, names, np.asarray(rows, np.float64))          # float64 input is narrowed to float32 on write
+    assert open(path, "rb").read() == want
+    back = GM.read_ply(path)
+    assert list(back) == names
+    np.testing.assert_array_equal(np.stack([back[n] for n in names], 1), np.asarray(rows, np.float32))
+
+    # a point cloud as the reference's storePly writes it (scene/dataset_readers.py: x y z nx ny nz float, red green blue
+    # uchar; 27-byte records), with a comment line and a second element after the vertices, as other writers add
+    head = (b"ply\nformat binary_little_endian 1.0\ncomment made by hand\nelement vertex 3\n"
+            b"property float x\nproperty float y\nproperty float z\nproperty float nx\nproperty float ny\nproperty float nz\n"
+            b"property uchar red\nproperty uchar green\nproperty uchar blue\nelement face 0\nproperty list uchar int vertex_indices\nend_header\n")
+    recs = [(0.5, 1.5, -1.0, 0.0, 0.0, 1.0, 255, 0, 17), (2.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1, 2, 3), (-7.0, 8.0, 9.0, 0.0, 1.0, 0.0, 128, 64, 32)]
+    body = b"".join(struct.pack("<6f3B", *r) for r in recs)
+    assert len(body) == 3 * 27
+    p2 = str(tmp_path / "points3D.ply")
+    open(p2, "wb").write(head + body)
+    v = GM.read_ply(p2)
+    np.testing.assert_array_equal(v["x"], np.float32([0.5, 2.0, -7.0]))
+    np.testing.assert_array_equal(v["nz"], np.float32([1.0, 0.0, 0.0]))
+    assert v["red"].dtype == np.uint8 and v["blue"].tolist() == [17, 3, 32] and v["green"].tolist() == [0, 2, 64]
+    # big-endian files of the same content read the same
+    p3 = str(tmp_path / "be.ply")
+    open(p3, "wb").write(head.replace(b"binary_little_endian", b"binary_big_endian") + b"".join(struct.pack(">6f3B", *r) for r in recs))
+    v3 = GM.read_ply(p3)
+    for k in v:
+        np.testing.assert_array_equal(v3[k], v[k])
+    # truncated header / wrong magic fail loudly
+    open(p3, "wb").write(b"ply\nformat binary_little_endian 1.0\nelement vertex 1\n")
+    with pytest.raises(ValueError):
+        GM.read_ply(p3)
+    open(p3, "wb").write(b"plx\n")
+    with pytest.raises(ValueError):
+        GM.read_ply(p3)
