@@ -60,6 +60,22 @@ __device__ __forceinline__ float row16_sum(float v)
     return v;
 }
 
+// the same for three values at once, as fused DPP adds (left to itself the compiler pairs two of the three into
+// v_pk_add_f32, which cannot take a DPP operand, and spends 5 instructions per step on moves).  A DPP read of a
+// register needs two wait states after the VALU write of it: s_nop 1 in front, and within the block every value is
+// touched again only after the other two.
+__device__ __forceinline__ void row16_sum3(float& a, float& b, float& c)
+{
+#define GS4D_DPP3(ctrl)                                                                   \
+    "v_add_f32_dpp %0, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"          \
+    "v_add_f32_dpp %1, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"          \
+    "v_add_f32_dpp %2, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm volatile("s_nop 1\n" GS4D_DPP3("quad_perm:[1,0,3,2]") GS4D_DPP3("quad_perm:[2,3,0,1]") GS4D_DPP3("row_shr:4")
+                 GS4D_DPP3("row_shr:8")
+                 : "+v"(a), "+v"(b), "+v"(c));
+#undef GS4D_DPP3
+}
+
 // lanes 0..31 receive a[l] + a[l+32], lanes 32..63 receive b[l-32] + b[l]
 __device__ __forceinline__ float fold32(float a, float b)
 {
@@ -210,16 +226,17 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
                 dL_dalpha *= T;
                 last_alpha = al;
                 dL_dalpha += (-T_final * rcp) * bg_dot_dpixel;
-                const f2 dL_dG = b.y * dL_dalpha;
-                const f2 gdx = Gm * dx;
-                const f2 gdy = Gm * dy;
-                const f2 dG_ddelx = -gdx * a.z - gdy * a.w;
-                const f2 dG_ddely = -gdy * b.x - gdx * a.w;
-                const f2 t = gdx * dL_dG;
+                // Every remaining sum is a moment of q = G * dL_dalpha over the wave's pixels: with d = mean - pixel,
+                //   dL_dG * dG_ddelx = -o q (cx dx + cy dy),  dL_dG * dG_ddely = -o q (cz dy + cy dx),
+                //   gdx dx dL_dG = o q dx^2,  gdx dy dL_dG = o q dx dy,  gdy dy dL_dG = o q dy^2
+                // (o = opacity, (cx, cy, cz) = conic: constants of the entry), so the pixels only form q, q d and q d d^T
+                // and the per-entry factors are applied ONCE, at the flush, to the sums.
+                const f2 q = Gm * dL_dalpha;
+                const f2 qx = q * dx, qy = q * dy;
                 const f2 p0 = w * dLp0, p1 = w * dLp1, p2 = w * dLp2, p3 = w * dLpd;
-                const f2 p4 = dL_dG * dG_ddelx, p5 = dL_dG * dG_ddely;     // x 0.5 W, 0.5 H at the flush
-                const f2 p6 = t * dx, p7 = t * dy, p8 = gdy * dy * dL_dG;  // x -0.5 at the flush
-                const f2 p9 = Gm * dL_dalpha;
+                const f2 p4 = qx, p5 = qy;
+                const f2 p6 = qx * dx, p7 = qx * dy, p8 = qy * dy;
+                const f2 p9 = q;
                 // the lane's two pixels, then the transposing reduction over the wave
                 const float u0 = fold32(p0.x + p0.y, p5.x + p5.y);   // lanes <32: v0, >=32: v5
                 const float u1 = fold32(p1.x + p1.y, p6.x + p6.y);   //            v1        v6
@@ -229,9 +246,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
                 float t0 = fold16(u0, u1);                           // rows: v0 v1 v5 v6
                 float t1 = fold16(u2, u3);                           // rows: v2 v3 v7 v8
                 float t2 = fold16(u4, u4);                           // rows: v4 v4 v9 v9
-                t0 = row16_sum(t0);
-                t1 = row16_sum(t1);
-                t2 = row16_sum(t2);
+                row16_sum3(t0, t1, t2);
                 if ((lane & 15) == 15) {
                     float* p = &s_part[wave][j][3 * (lane >> 4)];
                     p[0] = t0; p[1] = t1; p[2] = t2;
@@ -247,11 +262,16 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             float sl[NSLOT];
 #pragma unroll
             for (int q = 0; q < NSLOT; q++) sl[q] = (w0 ? s_part[0][e][q] : 0.f) + (w1 ? s_part[1][e][q] : 0.f);
-            // slots: [v0 v2 v4 | v1 v3 v4 | v5 v7 v9 | v6 v8 v9]
+            // slots: [v0 v2 v4 | v1 v3 v4 | v5 v7 v9 | v6 v8 v9]; v4.. are the moments of q (see above)
+            const float4 ea = s_a[e], eb = s_b[e];
+            const float o = eb.y, cx = ea.z, cy = ea.w, cz = eb.x;
+            const float Sx = sl[2], Sy = sl[6], Sxx = sl[9], Sxy = sl[7], Syy = sl[10], Sq = sl[8];
+            const float mx = -o * (cx * Sx + cy * Sy), my = -o * (cz * Sy + cy * Sx);
+            const float oh = -0.5f * o;
             float4* dst = rows + (size_t)(lo + e) * (GS4D_GRAD_ROW / 4);
             dst[0] = make_float4(sl[0], sl[3], sl[1], sl[4]);
-            dst[1] = make_float4(sl[2] * ddelx_dx, sl[6] * ddely_dy, -0.5f * sl[9], -0.5f * sl[7]);
-            dst[2] = make_float4(-0.5f * sl[10], sl[8], 0.f, 0.f);
+            dst[1] = make_float4(mx * ddelx_dx, my * ddely_dy, oh * Sxx, oh * Sxy);
+            dst[2] = make_float4(oh * Syy, Sq, 0.f, 0.f);
         }
     }
 }
