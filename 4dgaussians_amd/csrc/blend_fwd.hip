@@ -106,6 +106,10 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                 if (e < n) {
                     const float4 bx = s_box[e];
                     hit = bx.x <= rx1 && bx.y >= rx0 && bx.z <= ry1 && bx.w >= ry0;
+                    if (hit) {
+                        const float4 ea = s_a[e], eb = s_b[e];
+                        hit = !gs4d::alpha_support_misses_rect(ea.x, ea.y, ea.z, ea.w, eb.x, eb.y, rx0, rx1, ry0, ry1);
+                    }
                 }
                 hits[k] = __ballot(hit);
             }

@@ -168,4 +168,41 @@ __device__ __forceinline__ float4 alpha_support_box(float2 xy, float4 conic_opac
     return box;
 }
 
+// Exact version of the same question for one rectangle of pixel centres [rx0, rx1] x [ry0, ry1]: true only if the
+// splat PROVABLY reaches alpha >= 1/255 at no point of the rectangle (so at none of its pixels), i.e. if the minimum of
+// f(d) = 0.5 (cx dx^2 + cz dy^2) + cy dx dy over d = mean - pixel exceeds t = ln(255 opacity).  f is convex: its minimum
+// over the rectangle is 0 if the mean lies inside, otherwise it sits on one of the four edges, where it is a clamped
+// one-dimensional parabola.  The box above is what a diagonal, elongated splat wastes most on: a third of the
+// (wave, entry) visits that passed the box test at C2 blended nothing.  Conservative against float rounding: the
+// rectangle is inflated by 0.05 px, the threshold by 0.1 % + 1e-4, and 4e-6 of the magnitude of f's terms is taken off
+// (the kernels' own power carries ~1e-7 of them).  NaN or a non-positive-definite conic never culls.
+__device__ __forceinline__ bool alpha_support_misses_rect(float mx, float my, float cx, float cy, float cz, float opacity,
+                                                          float rx0, float rx1, float ry0, float ry1)
+{
+    if (!(cx > 0.0f && cz > 0.0f && cx * cz - cy * cy > 0.0f)) return false;
+    const float t = logf(255.0f * opacity);
+    if (!(t >= 0.0f)) return false;                                  // t < 0: the box is already empty; NaN: never cull
+    const float xl = mx - (rx1 + 0.05f), xh = mx - (rx0 - 0.05f);    // range of dx over the rectangle
+    const float yl = my - (ry1 + 0.05f), yh = my - (ry0 - 0.05f);
+    if (xl <= 0.0f && xh >= 0.0f && yl <= 0.0f && yh >= 0.0f) return false;    // mean inside
+    const float rcz = 1.0f / cz, rcx = 1.0f / cx;
+    float best = 3.0e38f;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        {   // edge dx = X
+            const float X = k ? xh : xl;
+            const float Y = fminf(fmaxf(-cy * X * rcz, yl), yh);
+            const float q = 0.5f * (cx * X * X + cz * Y * Y), m = cy * X * Y;
+            best = fminf(best, (q + m) - 4.0e-6f * (q + fabsf(m)));
+        }
+        {   // edge dy = Y
+            const float Y = k ? yh : yl;
+            const float X = fminf(fmaxf(-cy * Y * rcx, xl), xh);
+            const float q = 0.5f * (cx * X * X + cz * Y * Y), m = cy * X * Y;
+            best = fminf(best, (q + m) - 4.0e-6f * (q + fabsf(m)));
+        }
+    }
+    return best > t * 1.001f + 1.0e-4f;                              // false for NaN
+}
+
 }  // namespace gs4d
