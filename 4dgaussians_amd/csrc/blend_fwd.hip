@@ -131,9 +131,13 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                     bool use1 = !done1 && !(power.y > 0.0f) && !(alpha.y < (1.0f / 255.0f));
                     if (use0 && test_T.x < 0.0001f) { done0 = true; use0 = false; }
                     if (use1 && test_T.y < 0.0001f) { done1 = true; use1 = false; }
-                    if (__ballot(use0 || use1) != 0ull) {
+                    // No branch around an entry that no pixel of the wave blends (6 % of the visits once the exact
+                    // support test has run): a pixel that skips blends with alpha 0, the exact identity on its state for
+                    // finite colours / depths, and the straight-line body keeps the seven loop-carried registers in
+                    // place -- with a branch the compiler copied all of them on every visit (118 -> 110 us at C2).
+                    {
                         const float2 c = s_c[j];
-                        const f2 al = {use0 ? alpha.x : 0.f, use1 ? alpha.y : 0.f};   // skip == blend with alpha 0
+                        const f2 al = {use0 ? alpha.x : 0.f, use1 ? alpha.y : 0.f};
                         const f2 w = al * T;
                         C0 += b.w * w;
                         C1 += c.x * w;
@@ -143,9 +147,8 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                         T.y = use1 ? test_T.y : T.y;
                         last0 = use0 ? (uint32_t)(base + j + 1) : last0;
                         last1 = use1 ? (uint32_t)(base + j + 1) : last1;
-                    } else if (__ballot(!done0 || !done1) == 0ull) {
-                        all_done = true;  // every pixel of this wave is finished
                     }
+                    if (__ballot(!done0 || !done1) == 0ull) all_done = true;  // every pixel of this wave is finished
                 }
             }
         }
