@@ -1506,6 +1506,22 @@ size_t gs4d_deform_workspace_bytes(const gs4d_deform_desc* d, int P)
     return bytes;
 }
 
+// The plane-gradient pipeline (point kernel -> counting sort -> reduce) runs over batches of points so that its
+// per-sample scratch (gsix: 6 L C floats per point, 6 KB at C = 128) stays bounded: <= GS4D_HEX_BATCH_BYTES
+// (default 2 GiB) however many points the scene has.  A 5 M-point, C = 128 scene needed 31 GB before.
+static size_t hex_batch_points(const gs4d_deform_desc* d, size_t P)
+{
+    static const size_t limit = [] {
+        const char* e = getenv("GS4D_HEX_BATCH_BYTES");
+        const long long v = e ? atoll(e) : 0;
+        return v > 0 ? (size_t)v : ((size_t)2 << 30);
+    }();
+    size_t n = limit / ((size_t)d->L * 6 * d->C * sizeof(float));
+    n = n / 256 * 256;
+    if (n < 256) n = 256;
+    return n < P ? n : P;
+}
+
 static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l, size_t P, float** dO, float** dH1,
                           float** dZ, float** dT, float** dfeat, float** dxyz_hex, float** dtprime, float** gsix,
                           int** hist, int** rank, int** key, float4** rec, float** slabs, size_t* slab_floats_per_job, size_t* bytes)
@@ -1518,11 +1534,12 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     gs4d_obtain(p, *dfeat, P * l.F);
     gs4d_obtain(p, *dxyz_hex, P * 4);                  // (dx,dy,dz,dt') per point, normalised coordinates
     gs4d_obtain(p, *dtprime, 3 * ((P + 255) / 256) + 3);   // per-workgroup partial sums for the t' embedding
-    gs4d_obtain(p, *gsix, P * d->L * 6 * d->C);            // per-plane sample gradients, point kernel -> reduce kernel
+    const size_t HB = hex_batch_points(d, P);
+    gs4d_obtain(p, *gsix, HB * d->L * 6 * d->C);           // per-plane sample gradients of one batch, point kernel -> reduce kernel
     gs4d_obtain(p, *hist, (size_t)d->L * HEX_SORTS * hex_bins(d).nbins);
-    gs4d_obtain(p, *rank, (size_t)d->L * HEX_SORTS * P);
-    gs4d_obtain(p, *key, (size_t)d->L * HEX_SORTS * P);
-    gs4d_obtain(p, *rec, (size_t)d->L * HEX_SORTS * P);
+    gs4d_obtain(p, *rank, (size_t)d->L * HEX_SORTS * HB);
+    gs4d_obtain(p, *key, (size_t)d->L * HEX_SORTS * HB);
+    gs4d_obtain(p, *rec, (size_t)d->L * HEX_SORTS * HB);
     const size_t nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
     int kmax = l.F > l.head_in[0] ? l.F : l.head_in[0];
     for (int h = 0; h < NHEAD; h++) kmax = l.head_in[h] > kmax ? l.head_in[h] : kmax;
@@ -1819,27 +1836,35 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         const HexBins B = hex_bins(d);
         int lpp_shift = 0;
         while ((1 << lpp_shift) < d->C / 4) lpp_shift++;
-        const size_t threads = (size_t)P << lpp_shift;
-        hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P,
-                           d->C, d->L, lpp_shift, T, B, d->aabb, points, w.tprime, dfeat, l.F, (float4*)dxyz_hex, gsix,
-                           hist, rank, key);
-        hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS * d->L), dim3(1024), 0, s, B.nbins, hist);
-        hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, d->L, B.nbins, d->aabb, points,
-                           w.tprime, hist, rank, key, rec);
-        {
-            const int step_entries = (256 >> lanes_shift) * HEX_RUN;
-            const size_t per_wg = (size_t)step_entries * HEX_RPW;
-            const size_t lds = 2 * sizeof(float4) * step_entries + sizeof(float) * 4 * 256 + sizeof(int) * 3 * 64;
-            void (*kern)(int, int, int, PlaneTable, const float4*, const float*) =
-                lanes_shift == 2 ? hexplane_backward_reduce_kernel<2> : lanes_shift == 3 ? hexplane_backward_reduce_kernel<3> :
-                lanes_shift == 4 ? hexplane_backward_reduce_kernel<4> : lanes_shift == 5 ? hexplane_backward_reduce_kernel<5> :
-                                   hexplane_backward_reduce_kernel<6>;
-            static bool reduce_attr[8] = {};
-            if (!reduce_attr[lanes_shift]) {
-                GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-                reduce_attr[lanes_shift] = true;
-            }
-            hipLaunchKernelGGL(kern, dim3((unsigned)(((size_t)P + per_wg - 1) / per_wg), 6 * d->L), dim3(256), lds, s, P, d->C,
+        const size_t HB = hex_batch_points(d, (size_t)P);
+        const size_t hist_bytes = sizeof(int) * (size_t)d->L * HEX_SORTS * B.nbins;
+        const int step_entries = (256 >> lanes_shift) * HEX_RUN;
+        const size_t per_wg = (size_t)step_entries * HEX_RPW;
+        const size_t lds = 2 * sizeof(float4) * step_entries + sizeof(float) * 4 * 256 + sizeof(int) * 3 * 64;
+        void (*kern)(int, int, int, PlaneTable, const float4*, const float*) =
+            lanes_shift == 2 ? hexplane_backward_reduce_kernel<2> : lanes_shift == 3 ? hexplane_backward_reduce_kernel<3> :
+            lanes_shift == 4 ? hexplane_backward_reduce_kernel<4> : lanes_shift == 5 ? hexplane_backward_reduce_kernel<5> :
+                               hexplane_backward_reduce_kernel<6>;
+        static bool reduce_attr[8] = {};
+        if (!reduce_attr[lanes_shift]) {
+            GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+            reduce_attr[lanes_shift] = true;
+        }
+        // batches of HB points (one batch unless the scene is large, see hex_batch_points): the sorted records and
+        // gsix carry batch-local point indices, the plane gradients accumulate over the batches
+        for (size_t p0 = 0; p0 < (size_t)P; p0 += HB) {
+            const int n = (int)(((size_t)P - p0) < HB ? ((size_t)P - p0) : HB);
+            if (p0 > 0) GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, s));     // the first batch's zeros come from pe_backward
+            const float* pts_b = points + 3 * p0;
+            const float* tp_b = w.tprime + p0;
+            const size_t threads = (size_t)n << lpp_shift;
+            hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n,
+                               d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * l.F, l.F,
+                               (float4*)dxyz_hex + p0, gsix, hist, rank, key);
+            hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS * d->L), dim3(1024), 0, s, B.nbins, hist);
+            hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d->L, B.nbins, d->aabb,
+                               pts_b, tp_b, hist, rank, key, rec);
+            hipLaunchKernelGGL(kern, dim3((unsigned)(((size_t)n + per_wg - 1) / per_wg), 6 * d->L), dim3(256), lds, s, n, d->C,
                                d->L, T, rec, gsix);
         }
         GS4D_LAUNCH_CHECK("hexplane_backward", 0, s);
