@@ -28,6 +28,7 @@
 //    registers per cell, and only the combined rows go to memory with float atomics (the only
 //    non-deterministic sums in the library).
 #include <stdlib.h>
+#include <type_traits>
 
 #include "gs4d_internal.h"
 
@@ -930,34 +931,60 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
 }
 
 // ------------------------------------------------------------------ weight gradients (reduce over points)
-// slab[chunk][n][k] = sum over the chunk's rows of G[row][gcol0+n] * actX(X[row][xcol(k)]),  k == K is the bias column (x = 1)
+// slab[chunk][n][k] = sum over the chunk's rows of G[row][gcol0+n] * actX(X[row][xcol(k)]);  slab[chunk][n][Kp] = sum of G[row][gcol0+n]
 struct DwJob {
     const float* G; int ldg; int gcol0; int N;
     const float* X; int ldx; int x_nseg; int x_beg[3]; int x_len[3]; int K; int relu_x;
     int Kp;                              // K with every segment padded to 4 columns (the staged / slab k space; the source pads with zeros)
-    float* slabs; int kblocks;           // kblocks = ceil((K+1)/32); slab row pitch = 32*kblocks
+    float* slabs; int kblocks;           // kblocks = ceil(Kp/32) k-blocks of MFMA tiles; slab row pitch = 32*ceil((Kp+1)/32):
+                                         // column Kp of a slab row holds the bias partial (column sums of G, formed while G is staged)
     float* dW; float* db;                // final destinations [N][K], [N]
 };
 struct DwJobs { DwJob j[16]; int njobs, nz, nchunks; };
 
 // One workgroup = one (chunk of DW_ROWS_PER_WG point rows, job, slice of <= 6 k-blocks).  The rows are staged
 // through LDS in sub-blocks of DW_RB (every element of G and X is fetched from memory exactly once per
-// workgroup, coalesced, with ReLU / the bias column of ones / zero padding applied at the store), double
+// workgroup, coalesced, ReLU applied at the store), double
 // buffered, and the (n-block, k-block) output tiles are dealt round-robin to the four waves; both MFMA
 // operands are plain ds_read_b32 (row pitches are 32 mod 64 floats, so the two k halves of a wave use
 // disjoint banks).  The earlier version fetched operands per wave straight from global memory: every G block
 // was read by two waves and every X block by two more, 1.8 GB of L2 traffic per step for 0.4 GB of data.
 #define DW_RB 16
+#define DW_DEPTH 2              // sub-blocks of global loads in flight per thread (even: the LDS double buffer follows the parity)
 #define DW_NG (DW_RB / 16)       // float4s of G per thread and sub-block
 #define DW_NX (3 * DW_RB / 16)   // float4s of X
 #define DW_GP 96
 #define DW_XP 224
 #define DW_XCOLS 192
-__global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
+// The MFMAs of one staged sub-block for a wave that owns CNT tiles (same n-block, CNT k-blocks): every LDS operand of
+// the sub-block is requested first, then the MFMAs issue back to back.  Written with run-time `if (cnt > 1)` tests
+// inside the step loop, the compiler emitted ds_read -> s_waitcnt lgkmcnt(0) -> v_mfma for every single product: the LDS
+// latency was exposed 8..24 times per sub-block and a job of 3 tiles took as long as one of 10.
+template <int CNT>
+__device__ __forceinline__ void dw_mfma_subblock(const float* __restrict__ ga, const float* __restrict__ xb, int kstep,
+                                                 f32x16 (&acc)[3])
+{
+    float a[DW_RB / 2], b[CNT][DW_RB / 2];
+#pragma unroll
+    for (int st = 0; st < DW_RB / 2; st++) {
+        a[st] = ga[2 * st * DW_GP];
+#pragma unroll
+        for (int c = 0; c < CNT; c++) b[c][st] = xb[2 * st * DW_XP + c * kstep];
+    }
+#pragma unroll
+    for (int st = 0; st < DW_RB / 2; st++) {
+#pragma unroll
+        for (int c = 0; c < CNT; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[st], b[c][st], acc[c], 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void dw_partial_kernel(int P, DwJobs jobs)
 {
     __shared__ float sG[2][DW_RB * DW_GP];
     __shared__ float sX[2][DW_RB * DW_XP];
-    __shared__ int s_xcol[DW_XCOLS / 4];
+    // the column table is only read during set-up and lives in staging buffer 1, which is first written after the
+    // prologue's barrier (40 960 bytes of LDS in all; four workgroups per CU would fit, but not their registers)
+    int* s_xcol = reinterpret_cast<int*>(&sX[1][0]);
     // 1-D grid, XCD-aware: consecutive workgroup ids go to different XCDs (each with its own L2), so the
     // jobs of one chunk -- which re-read the same rows of Z / dH1 / H1 / dO -- are placed 8 ids apart:
     // same XCD, adjacent in dispatch order.
@@ -972,19 +999,22 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     const int kb_first = zblk * 6;
     const int nkb = min(6, J.kblocks - kb_first);
     if (nkb <= 0) return;                                   // uniform
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
     const int nn = (J.N + 31) >> 5;                         // 1 or 2 n-blocks
     const int ntiles = nn * nkb;                            // <= 12; wave w owns tiles w, w+4, w+8 (all with n-block w % nn)
     const int vw = (wave + chunk) & 3;                      // rotate the tile deal so the 3-tile waves do not all sit on one SIMD
-    const int cnt = (ntiles - vw + 3) >> 2;
+    const int cnt = __builtin_amdgcn_readfirstlane((ntiles - vw + 3) >> 2);
     const int nb = vw % nn;
     const int rbeg = chunk * DW_ROWS_PER_WG, rend = min(P, rbeg + DW_ROWS_PER_WG);
 
     // staged 4-column group -> source column of X.  Segments begin on 4-float boundaries and every segment but
-    // the last is a multiple of 4 long (checked on the host), so a group is one aligned float4 of the source row;
-    // the group holding column K is patched per component (ones for the bias column, zeros after it; the
-    // source row is padded, so the over-read stays inside it).  -1: group is entirely past K.
+    // the last is a multiple of 4 long (checked on the host), so a group is one aligned float4 of the source row.
+    // Nothing is patched: a staged column at or past K (the source row is padded, so the over-read stays inside
+    // it; -1: the group is entirely past Kp and is not loaded at all) only ever meets slab columns that
+    // dw_reduce_kernel does not read -- every output (n, k) is a sum of products of column k alone.  The same
+    // holds for columns of G at or past N.  The staging used to zero / one-fill per component; that VALU work
+    // cost as much issue time as the MFMAs (a job of 3 tiles and one of 10 both took 35-45 us on their own).
     for (int c = tid; c < DW_XCOLS / 4; c += 256) {
         const int k = kb_first * 32 + 4 * c;
         int src = -1;
@@ -997,7 +1027,7 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
     }
     __syncthreads();
     // fixed staging assignments of this thread: one float4 of G (16 rows x 16 groups), three of X (16 x 48)
-    int xoff[DW_NX], xrow[DW_NX], xdst[DW_NX], xk[DW_NX];
+    int xoff[DW_NX], xrow[DW_NX], xdst[DW_NX];
     bool xlive[DW_NX];
 #pragma unroll
     for (int i = 0; i < DW_NX; i++) {
@@ -1006,95 +1036,109 @@ __global__ __launch_bounds__(256) void dw_partial_kernel(int P, DwJobs jobs)
         xrow[i] = row;
         xoff[i] = s_xcol[grp];
         xdst[i] = row * DW_XP + 4 * grp;
-        xk[i] = kb_first * 32 + 4 * grp;                    // k of the group's first column
         xlive[i] = 4 * grp < nkb * 32;                      // groups of k-blocks this slice does not own are never read
     }
     const int ggrp = tid & 15, grow = tid >> 4;             // G: row grow, columns 4*ggrp .. +3
     const float* __restrict__ Gp = J.G + J.gcol0 + 4 * min(ggrp, (J.N - 1) >> 2);
     const float* __restrict__ Xp = J.X;
-    const int ldg = J.ldg, ldx = J.ldx, N = J.N, K = J.Kp;
+    const int ldg = J.ldg, ldx = J.ldx;
     const bool relu = J.relu_x != 0;
 
-    float4 gvs[2][DW_NG], xvs[2][DW_NX];     // two register sets: loads run two sub-blocks ahead of the MFMAs
+    float4 gvs[DW_DEPTH][DW_NG], xvs[DW_DEPTH][DW_NX];     // register ring: loads run DW_DEPTH sub-blocks ahead of the MFMAs
+    // Every fetch issues the same DW_NG + DW_NX loads, unconditionally (a slot with nothing to stage re-reads the
+    // slice's first group, rows past the chunk's end are clamped): with loads under branches the compiler cannot
+    // count what is outstanding and put s_waitcnt vmcnt(0) in front of every LDS store, i.e. each step also waited
+    // for the loads issued one step earlier for two steps later -- the ring was one step deep, not DW_DEPTH.
+    int xsrc[DW_NX];
+#pragma unroll
+    for (int i = 0; i < DW_NX; i++) xsrc[i] = (xlive[i] && xoff[i] >= 0) ? xoff[i] : s_xcol[0];
     auto fetch = [&](float4 (&gv)[DW_NG], float4 (&xv)[DW_NX], int r0) {
 #pragma unroll
         for (int i = 0; i < DW_NG; i++)
             gv[i] = *reinterpret_cast<const float4*>(Gp + (size_t)min(r0 + grow + 16 * i, rend - 1) * ldg);
 #pragma unroll
         for (int i = 0; i < DW_NX; i++)
-            if (xlive[i] && xoff[i] >= 0)
-                xv[i] = *reinterpret_cast<const float4*>(Xp + (size_t)min(r0 + xrow[i], rend - 1) * ldx + xoff[i]);
+            xv[i] = *reinterpret_cast<const float4*>(Xp + (size_t)min(r0 + xrow[i], rend - 1) * ldx + xsrc[i]);
     };
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);          // bias partial: column sums of this thread's rows of G
     auto stash = [&](const float4 (&gv)[DW_NG], const float4 (&xv)[DW_NX], int r0, int buf) {
 #pragma unroll
         for (int i = 0; i < DW_NG; i++) {
-            const bool rok = r0 + grow + 16 * i < rend;
-            float g4[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) g4[q] = (rok && 4 * ggrp + q < N) ? g4[q] : 0.f;
-            *reinterpret_cast<float4*>(&sG[buf][(grow + 16 * i) * DW_GP + 4 * ggrp]) = make_float4(g4[0], g4[1], g4[2], g4[3]);
+            float4 g4 = gv[i];
+            if (r0 + grow + 16 * i >= rend) g4 = make_float4(0.f, 0.f, 0.f, 0.f);   // rows past the end were clamped, not skipped
+            bsum.x += g4.x; bsum.y += g4.y; bsum.z += g4.z; bsum.w += g4.w;
+            *reinterpret_cast<float4*>(&sG[buf][(grow + 16 * i) * DW_GP + 4 * ggrp]) = g4;
         }
 #pragma unroll
         for (int i = 0; i < DW_NX; i++) {
             if (!xlive[i]) continue;
-            float x4[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int k = xk[i] + q;
-                float v = relu ? fmaxf(x4[q], 0.f) : x4[q];
-                x4[q] = (xoff[i] >= 0 && k < K) ? v : (k == K ? 1.f : 0.f);
-            }
-            *reinterpret_cast<float4*>(&sX[buf][xdst[i]]) = make_float4(x4[0], x4[1], x4[2], x4[3]);
+            float4 v = xv[i];
+            if (relu) v = make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));   // uniform per job
+            *reinterpret_cast<float4*>(&sX[buf][xdst[i]]) = v;
         }
     };
 
-    f32x16 acc[3] = {{0}, {0}, {0}};
-    fetch(gvs[0], xvs[0], rbeg);
-    if (rbeg + DW_RB < rend) fetch(gvs[1], xvs[1], rbeg + DW_RB);
-    stash(gvs[0], xvs[0], rbeg, 0);
-    __syncthreads();
-    if (rbeg + 2 * DW_RB < rend) fetch(gvs[0], xvs[0], rbeg + 2 * DW_RB);
     const float* ga0 = &sG[0][half * DW_GP + nb * 32 + l31];
     const float* xb0 = &sX[0][half * DW_XP + (vw / nn) * 32 + l31];
     const int kstep = (4 / nn) * 32;                        // k-block distance between the wave's consecutive tiles
-    for (int r = rbeg; r < rend; r += 2 * DW_RB) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int rr = r + u * DW_RB;
-            if (rr >= rend) break;                          // uniform
-            if (cnt > 0) {
-                const float* ga = ga0 + u * (DW_RB * DW_GP);
-                const float* xb = xb0 + u * (DW_RB * DW_XP);
-#pragma unroll
-                for (int st = 0; st < DW_RB / 2; st++) {
-                    const float a = ga[2 * st * DW_GP];
-                    const float b0 = xb[2 * st * DW_XP];
-                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-                    if (cnt > 1) {
-                        const float b1 = xb[2 * st * DW_XP + kstep];
-                        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
-                    }
-                    if (cnt > 2) {
-                        const float b2 = xb[2 * st * DW_XP + 2 * kstep];
-                        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b2, acc[2], 0, 0, 0);
-                    }
-                }
-            }
-            if (rr + DW_RB < rend) stash(gvs[u ^ 1], xvs[u ^ 1], rr + DW_RB, u ^ 1);
-            if (rr + 3 * DW_RB < rend) fetch(gvs[u ^ 1], xvs[u ^ 1], rr + 3 * DW_RB);
-            __syncthreads();
-        }
-    }
-    const int pitch = 32 * J.kblocks;
+    const int pitch = 32 * ((J.Kp + 1 + 31) >> 5);
     float* slab = J.slabs + (size_t)chunk * 64 * pitch;
+    // The whole row loop is instantiated per tile count of the wave (0..3, wave-uniform) and selected ONCE: a run-time
+    // count inside the loop made the compiler shuttle all 48 accumulator registers between the branches' copies on
+    // every step.
+    auto run_rows = [&](auto tag) {
+        constexpr int CNT = decltype(tag)::value;
+        f32x16 acc[3] = {{0}, {0}, {0}};
 #pragma unroll
-    for (int t = 0; t < 3; t++) {
-        if (t >= cnt) continue;
-        const int kb = kb_first + vw / nn + t * (4 / nn);
+        for (int i = 0; i < DW_DEPTH; i++) fetch(gvs[i], xvs[i], rbeg + i * DW_RB);
+        stash(gvs[0], xvs[0], rbeg, 0);
+        __syncthreads();
+        fetch(gvs[0], xvs[0], rbeg + DW_DEPTH * DW_RB);
+        for (int r = rbeg; r < rend; r += DW_DEPTH * DW_RB) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            slab[(size_t)n * pitch + kb * 32 + l31] = acc[t][r];
+            for (int u = 0; u < DW_DEPTH; u++) {
+                const int rr = r + u * DW_RB;
+                if (rr >= rend) break;                      // uniform
+                if constexpr (CNT > 0)
+                    dw_mfma_subblock<CNT>(ga0 + (u & 1) * (DW_RB * DW_GP), xb0 + (u & 1) * (DW_RB * DW_XP), kstep, acc);
+                // ring slot (u+1) holds sub-block rr + DW_RB (fetched DW_DEPTH steps ago): into the other LDS buffer,
+                // then the slot is refilled with the sub-block DW_DEPTH further on
+                if (rr + DW_RB < rend) stash(gvs[(u + 1) % DW_DEPTH], xvs[(u + 1) % DW_DEPTH], rr + DW_RB, (u + 1) & 1);
+                fetch(gvs[(u + 1) % DW_DEPTH], xvs[(u + 1) % DW_DEPTH], rr + (DW_DEPTH + 1) * DW_RB);   // past the end: clamped rows, never staged
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < CNT; t++) {
+            const int kb = kb_first + vw / nn + t * (4 / nn);
+            if (kb * 32 + l31 == J.Kp) continue;            // that column is the bias partial's (written below)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int n = nb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                slab[(size_t)n * pitch + kb * 32 + l31] = acc[t][r];
+            }
+        }
+    };
+    if (cnt >= 3) run_rows(std::integral_constant<int, 3>{});
+    else if (cnt == 2) run_rows(std::integral_constant<int, 2>{});
+    else if (cnt == 1) run_rows(std::integral_constant<int, 1>{});
+    else run_rows(std::integral_constant<int, 0>{});
+    // bias partial: the 16 threads that staged the rows of one column group add up through LDS (fixed order)
+    if (zblk == 0) {
+        __syncthreads();                                    // the staging buffers are free
+        float4* red = reinterpret_cast<float4*>(&sX[0][0]);
+        red[grow * 16 + ggrp] = bsum;
+        __syncthreads();
+        if (tid < 16) {
+            float4 t4 = red[tid];
+            for (int g = 1; g < 16; g++) {
+                const float4 u = red[g * 16 + tid];
+                t4.x += u.x; t4.y += u.y; t4.z += u.z; t4.w += u.w;
+            }
+            const float o4[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (4 * tid + q < J.N) slab[(size_t)(4 * tid + q) * pitch + J.Kp] = o4[q];
         }
     }
 }
@@ -1103,7 +1147,7 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(int nchunks, DwJobs jobs
 {
     __shared__ float part[4][64];
     const DwJob& J = jobs.j[blockIdx.y];
-    const int pitch = 32 * J.kblocks;
+    const int pitch = 32 * ((J.Kp + 1 + 31) >> 5);
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;          // output of the block, chunk quarter
     const int idx = blockIdx.x * 64 + o;
     const int total = J.N * (J.K + 1);
@@ -1784,7 +1828,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         q.G = dcur; q.ldg = dcur_ld; q.gcol0 = 0; q.N = WIDTH;
         q.X = i == 0 ? w.feat : w.trunk[i - 1]; q.ldx = K; q.x_nseg = 1; q.x_beg[0] = 0; q.x_len[0] = K; q.K = K;
         q.relu_x = i > 0;
-        q.Kp = K; q.kblocks = (K + 1 + 31) / 32; q.slabs = slabs + slab_per_job * (2 * NHEAD + i);
+        q.Kp = K; q.kblocks = (K + 31) / 32; q.slabs = slabs + slab_per_job * (2 * NHEAD + i);
         q.dW = g->trunk_w[i]; q.db = g->trunk_b[i];
         add_dw(q);
         dcur = dst;
@@ -1800,14 +1844,14 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         a.K = l.head_in[h]; a.relu_x = 1;
         a.Kp = 0;
         for (int sg = 0; sg < a.x_nseg; sg++) a.Kp += pad4(a.x_len[sg]);
-        a.kblocks = (a.Kp + 1 + 31) / 32;
+        a.kblocks = (a.Kp + 31) / 32;
         a.slabs = slabs + slab_per_job * h; a.dW = g->head_w1[h]; a.db = g->head_b1[h];
         add_dw(a);
         DwJob b = {};
         b.G = dO; b.ldg = OUT_LD; b.gcol0 = l.head_ocol[h]; b.N = l.head_out[h];
         if (h == 3 && fused_heads && !d->no_dshs) { b.G = dL_dshs; b.ldg = 48; b.gcol0 = 0; }   // dO's SH columns ARE the upstream gradient: not copied
         b.X = w.H1; b.ldx = NHEAD * WIDTH; b.x_nseg = 1; b.x_beg[0] = h * WIDTH; b.x_len[0] = WIDTH; b.K = WIDTH;
-        b.relu_x = 1; b.Kp = WIDTH; b.kblocks = (WIDTH + 1 + 31) / 32;
+        b.relu_x = 1; b.Kp = WIDTH; b.kblocks = (WIDTH + 31) / 32;
         b.slabs = slabs + slab_per_job * (NHEAD + h); b.dW = g->head_w2[h]; b.db = g->head_b2[h];
         add_dw(b);
     }
