@@ -28,6 +28,7 @@
 //    registers per cell, and only the combined rows go to memory with float atomics (the only
 //    non-deterministic sums in the library).
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #include "gs4d_internal.h"
@@ -930,6 +931,105 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(int P, GemmJobs jobs)
     }
 }
 
+// The same product for the shape every trunk layer but a wide first one has, in both directions: K = 64 contiguous
+// columns of A, N <= 64.  A wave's step is one 32-row tile: the NEXT tile's eight float4 of A and (MASK) this tile's
+// 32 mask values are requested first, unconditionally (clamped rows: the compiler can then count the outstanding loads
+// instead of draining them), the 64 MFMAs run without a branch, the epilogue follows.  In the general kernel above the
+// row-block / group bookkeeping sits inside the MFMA loop as run-time tests and costs ~220 register copies and a
+// full wait per group; at this shape that was 25 us per launch at C2 for 10 us of traffic.
+template <bool RELU, bool MASK>
+__global__ __launch_bounds__(256) void gemm64_rows_kernel(int P, GemmJobs jobs)
+{
+    __shared__ float4 sB4[8 * 2 * 64];                  // [m][h][j] -> the four k = 8m + 4h + q of column j
+    int job_v = 0;
+    while (job_v < 7 && (int)blockIdx.x >= jobs.wg_begin[job_v + 1]) job_v++;
+    const int job = __builtin_amdgcn_readfirstlane(job_v);
+    const GemmJob& J = jobs.j[job];
+    const int wg = blockIdx.x - jobs.wg_begin[job], nwg = jobs.wg_begin[job + 1] - jobs.wg_begin[job];
+    const int N = J.N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {   // stage B: thread -> (column j, eight consecutive k); zero columns past N
+        const float* src = J.B[0];
+        const int ld = J.b_ld[0], c0 = J.b_col0[0];
+        for (int e = tid; e < 64 * 8; e += 256) {
+            const int j = e & 63, kb = e >> 6;          // k = 8 kb .. 8 kb + 7
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int k = 8 * kb + q, jc = min(j, N - 1);
+                v[q] = J.b_transposed ? src[(size_t)(c0 + jc) * ld + k] : src[(size_t)k * ld + c0 + jc];
+                if (j >= N) v[q] = 0.f;
+            }
+            sB4[(kb * 2 + 0) * 64 + j] = make_float4(v[0], v[1], v[2], v[3]);
+            sB4[(kb * 2 + 1) * 64 + j] = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+    __syncthreads();
+    const int i = lane & 31, khalf = lane >> 5, col = i;
+    const int ntile = (P + 31) >> 5;                    // 32-row tiles; wave w of workgroup g takes tiles 4 (g + s nwg) + w
+    const int tstride = 4 * nwg;
+    int tile = 4 * wg + wave;
+    if (tile >= ntile) return;                          // no barrier below
+    const float* __restrict__ Ab = J.A + J.a_beg[0] + 4 * khalf;
+    const int lda = J.lda;
+    const float bias0 = (J.bias && col < N) ? J.bias[col] : 0.f;
+    const float bias1 = (J.bias && col + 32 < N) ? J.bias[col + 32] : 0.f;
+    float* __restrict__ Y = J.Y + J.ycol0;
+    const int ldy = J.ldy;
+    const float* __restrict__ Mk = MASK ? J.mask + J.mcol0 : nullptr;
+    const int ldm = J.ldm;
+    const float4* bcol = sB4 + khalf * 64 + col;
+    const int c0m = min(col, N - 1), c1m = min(col + 32, N - 1);
+
+    float4 a[8], an[8];
+    {
+        const float* arow = Ab + (size_t)min(32 * tile + i, P - 1) * lda;
+#pragma unroll
+        for (int m = 0; m < 8; m++) a[m] = *reinterpret_cast<const float4*>(arow + 8 * m);
+    }
+    for (; tile < ntile; tile += tstride) {
+        {   // next tile's A (clamped to the last tile: re-read, never used)
+            const float* arow = Ab + (size_t)min(32 * min(tile + tstride, ntile - 1) + i, P - 1) * lda;
+#pragma unroll
+            for (int m = 0; m < 8; m++) an[m] = *reinterpret_cast<const float4*>(arow + 8 * m);
+        }
+        const int row0 = 32 * tile + 4 * khalf;
+        float m0[16], m1[16];
+        if (MASK) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const float* mrow = Mk + (size_t)min(row0 + (r & 3) + 8 * (r >> 2), P - 1) * ldm;
+                m0[r] = mrow[c0m];
+                m1[r] = mrow[c1m];
+            }
+        }
+        f32x16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            const float4 b0 = bcol[m * 128], b1 = bcol[m * 128 + 32];
+            float av[4] = {a[m].x, a[m].y, a[m].z, a[m].w};
+            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (RELU) av[q] = fmaxf(av[q], 0.f);
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv0[q], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv1[q], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            float v0 = acc0[r] + bias0, v1 = acc1[r] + bias1;
+            if (MASK) { v0 = m0[r] > 0.f ? v0 : 0.f; v1 = m1[r] > 0.f ? v1 : 0.f; }
+            if (row < P && col < N) Y[(size_t)row * ldy + col] = v0;
+            if (row < P && col + 32 < N) Y[(size_t)row * ldy + col + 32] = v1;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; m++) a[m] = an[m];
+    }
+}
+
+
 // ------------------------------------------------------------------ weight gradients (reduce over points)
 // slab[chunk][n][k] = sum over the chunk's rows of G[row][gcol0+n] * actX(X[row][xcol(k)]);  slab[chunk][n][Kp] = sum of G[row][gcol0+n]
 struct DwJob {
@@ -1493,6 +1593,24 @@ static int launch_gemm(int P, GemmJobs& jobs, int njobs, hipStream_t s)
             gs4d_set_error("deform gemm: bad fused job %d", i);
             return GS4D_EINVAL;
         }
+    }
+    // every job K = 64 contiguous columns: the dedicated kernel (GS4D_DEFORM_GEMM=general keeps the general one)
+    bool k64 = !fuse;
+    for (int i = 0; i < njobs; i++) k64 = k64 && jobs.j[i].a_nseg == 1 && jobs.j[i].a_len[0] == 64 && jobs.j[i].b_nseg == 1;
+    static const bool force_general = [] { const char* e = getenv("GS4D_DEFORM_GEMM"); return e && !strcmp(e, "general"); }();
+    if (k64 && !force_general) {
+        void (*k)(int, GemmJobs) = relu ? (mask ? gemm64_rows_kernel<true, true> : gemm64_rows_kernel<true, false>)
+                                        : (mask ? gemm64_rows_kernel<false, true> : gemm64_rows_kernel<false, false>);
+        // persistent grid: 2 workgroups (8 waves: the kernel holds 172-224 VGPRs) per CU shared between the jobs, at most one wave per 32-row tile
+        const int ntile = (P + 31) / 32;
+        int per = (GEMM_CUS * 2 + njobs - 1) / njobs;
+        if (per > (ntile + 3) / 4) per = (ntile + 3) / 4;
+        if (per < 1) per = 1;
+        jobs.wg_begin[0] = 0;
+        for (int i = 0; i < 8; i++) jobs.wg_begin[i + 1] = jobs.wg_begin[i] + (i < njobs ? per : 0);
+        hipLaunchKernelGGL(k, dim3(jobs.wg_begin[8]), dim3(256), 0, s, P, jobs);
+        GS4D_LAUNCH_CHECK("deform_gemm64", 0, s);
+        return GS4D_OK;
     }
     const size_t lds = gemm_lds_bytes(Kpmax) + (fuse ? sizeof(float) * (64 * 64 + 4 * 32 * FUSE_TP) : 0);
     void (*kern)(int, GemmJobs) = fuse ? gemm_rows_kernel<true, false, true>
