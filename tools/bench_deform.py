@@ -15,6 +15,17 @@ net.deformation_net.set_aabb([1.3] * 3, [-1.3] * 3)
 net = net.to(dev)
 x = [torch.rand(P, 3, device=dev) * 2.6 - 1.3, torch.randn(P, 3, device=dev) - 3, torch.randn(P, 4, device=dev), torch.randn(P, 1, device=dev),
      torch.randn(P, 16, 3, device=dev) * 0.3]
+if os.environ.get("SORTED"):
+    q = ((x[0] + 1.3) / 2.6 * 1023).clamp(0, 1023).long()
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    order = torch.argsort(code)
+    x = [t[order].contiguous() for t in x]
 for t in x:
     t.requires_grad_(True)
 tm, fc = torch.full((P, 1), 0.4, device=dev), torch.zeros(P, 1, device=dev)
