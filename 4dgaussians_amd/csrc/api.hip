@@ -148,7 +148,6 @@ BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes)
     gs4d_obtain(chunk, b.keys_tmp[1], R);
     gs4d_obtain(chunk, b.values_tmp[0], R);
     gs4d_obtain(chunk, b.values_tmp[1], R);
-    gs4d_obtain(chunk, b.inv, R);
     gs4d_obtain(chunk, b.hist, (size_t)256 * gs4d_sort_blocks(R) + 256);
     b.sorted = passes > 0 ? (passes - 1) & 1 : 0;
     return b;
@@ -428,11 +427,9 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
     if (!inst_grad) { gs4d_set_error("backward scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)inst_grad & 255) { gs4d_set_error("backward scratch must be 256-byte aligned"); return GS4D_EINVAL; }
 
-    int rc = gs4d_launch_inverse_permutation(R, width, height, radii, g, b, gs4d_backward_big_count(inst_grad, R), debug, s);
-    if (rc) return rc;
     const float* features = colors_precomp ? colors_precomp : g.rgb;
-    rc = gs4d_launch_blend_backward(width, height, R, g, b, im, features, background, dL_dpix, dL_dpix_depth,
-                                        inst_grad, debug, s);
+    int rc = gs4d_launch_blend_backward(width, height, R, radii, g, b, im, features, background, dL_dpix, dL_dpix_depth,
+                                        inst_grad, gs4d_backward_big_count(inst_grad, R), debug, s);
     if (rc) return rc;
     const float* cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
     return gs4d_launch_geom_backward(P, D, M, R, width, height, means3D, radii, shs, scales, rotations,

@@ -492,43 +492,24 @@ __global__ __launch_bounds__(256) void segment_depth_sort_kernel(const uint2* __
     }
 }
 
-// ------------------------------------------------------------------ tile ranges + inverse permutation
-// ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand by emit_keys_kernel); inv[emission slot] = sorted
-// position, recovered from the key's tile id and the Gaussian's rectangle (no extra sort payload).
-template <bool RANGES, bool INV>
-__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, int gx, int gy,
-                                                          const uint64_t* __restrict__ keys_sorted,
-                                                          const uint32_t* __restrict__ point_list,
-                                                          const float2* __restrict__ means2D,
-                                                          const int* __restrict__ radii,
-                                                          const uint32_t* __restrict__ point_offsets,
-                                                          uint2* __restrict__ ranges, uint32_t* __restrict__ inv,
-                                                          uint32_t* __restrict__ clear_word)
+// ------------------------------------------------------------------ tile ranges (six-pass LSD order only)
+// ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand by emit_keys_kernel)
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint64_t* __restrict__ keys_sorted,
+                                                          uint2* __restrict__ ranges)
 {
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= R) return;
-    if (idx == 0 && clear_word) *clear_word = 0u;
     const uint32_t tile = (uint32_t)(keys_sorted[idx] >> 32);
-    if (RANGES) {
-        if (idx == 0)
-            ranges[tile].x = 0;
-        else {
-            const uint32_t prev = (uint32_t)(keys_sorted[idx - 1] >> 32);
-            if (tile != prev) {
-                ranges[prev].y = idx;
-                ranges[tile].x = idx;
-            }
+    if (idx == 0)
+        ranges[tile].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys_sorted[idx - 1] >> 32);
+        if (tile != prev) {
+            ranges[prev].y = idx;
+            ranges[tile].x = idx;
         }
-        if (idx == R - 1) ranges[tile].y = R;
     }
-    if (!INV) return;
-    const uint32_t g = point_list[idx];
-    const float2 m = means2D[g];
-    int x0, y0, x1, y1;
-    tile_rect(m.x, m.y, radii[g], gx, gy, x0, y0, x1, y1);
-    const int ty = (int)(tile / (uint32_t)gx), tx = (int)(tile % (uint32_t)gx);
-    const uint32_t first = g ? point_offsets[g - 1] : 0u;
-    inv[first + (uint32_t)((ty - y0) * (x1 - x0) + (tx - x0))] = idx;
+    if (idx == R - 1) ranges[tile].y = R;
 }
 
 }  // namespace
@@ -608,28 +589,12 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
         if (rc) return rc;
     }
     if (where != b.sorted) { gs4d_set_error("binning: sorted lists ended in buffer %d, layout expects %d", where, b.sorted); return GS4D_EINVAL; }
-    // ranges: already written by tile_bounds_kernel in tile-first order.  The inverse permutation `inv` is only read
-    // by the backward pass and is built there (gs4d_launch_inverse_permutation): a forward-only frame does not pay for it.
+    // ranges: already written by tile_bounds_kernel in tile-first order
     if (!gs4d_sort_tile_first()) {
         GS4D_PROF("tile_ranges", s);
-        hipLaunchKernelGGL((tile_ranges_kernel<true, false>), dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
-                           b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, im.ranges, b.inv,
-                           (uint32_t*)nullptr);
+        hipLaunchKernelGGL(tile_ranges_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.keys_sorted(),
+                           im.ranges);
         GS4D_LAUNCH_CHECK("tile_ranges", debug, s);
     }
-    return GS4D_OK;
-}
-
-// inv[emission slot] = sorted position, for the per-Gaussian gather of the backward pass
-int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b,
-                                    uint32_t* clear_word, int debug, hipStream_t s)
-{
-    if (R <= 0) return GS4D_OK;
-    const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
-    GS4D_PROF("inverse_permutation", s);
-    hipLaunchKernelGGL((tile_ranges_kernel<false, true>), dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, gx, gy,
-                       b.keys_sorted(), b.point_list(), g.means2D, radii, g.point_offsets, (uint2*)nullptr, b.inv,
-                       clear_word);
-    GS4D_LAUNCH_CHECK("inverse_permutation", debug, s);
     return GS4D_OK;
 }

@@ -19,10 +19,10 @@
 //  * lanes 15/31/47/63 store the wave partial into LDS (one private row per wave: no LDS atomics);
 //    a per-wave bit mask records which list entries were written, so nothing is zero-filled;
 //  * after a batch of <= 256 list entries the two wave partials are added in fixed order and
-//    the tile's partial row (12 floats, 10 used) is written to inst_grad[sorted position],
-//    i.e. one coalesced 48-byte row per (tile, Gaussian) instance and NO global atomics;
-//  * the per-Gaussian kernel (geom_bwd.hip) gathers a Gaussian's rows through the inverse
-//    permutation in fixed order, so gradients are bitwise reproducible run to run.
+//    the tile's partial row (12 floats, 10 used) is written to inst_grad[emission slot of the (Gaussian, tile)
+//    pair], i.e. one 48-byte row per instance and NO global atomics;
+//  * the per-Gaussian kernel (geom_bwd.hip) sums a Gaussian's rows -- contiguous, in emission order -- so
+//    gradients are bitwise reproducible run to run.
 // Rows of list entries that no pixel of the tile reached (position >= tile_max_contrib) are
 // zero-filled without being evaluated.  1/(1-alpha) uses v_rcp_f32 (1 ulp) where the reference
 // divides; gradient tolerance is 1e-4 relative.
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const uint32_t* __restrict__ tile_max_contrib, const float* __restrict__ bg, const float2* __restrict__ means2D,
     const float4* __restrict__ conic_opacity, const float* __restrict__ colors, const float* __restrict__ depths,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
-    const float* __restrict__ dL_dpixel_depths, float* __restrict__ inst_grad)
+    const float* __restrict__ dL_dpixel_depths, const int* __restrict__ radii, const uint32_t* __restrict__ point_offsets,
+    int gy, float* __restrict__ inst_grad, uint32_t* __restrict__ clear_word)
 {
     __shared__ float4 s_a[BWD_BATCH];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[BWD_BATCH];   // conic.z, opacity, depth, r
@@ -109,10 +110,12 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     __shared__ float4 s_box[BWD_BATCH]; // x - hx, x + hx, y - hy, y + hy: where alpha can reach 1/255
     __shared__ float s_part[2][BWD_BATCH][NSLOT];  // per-wave partial sums of the current batch (24 KB)
     __shared__ unsigned long long s_mask[2][BWD_BATCH / 64];        // which entries of the batch a wave has written
+    __shared__ uint32_t s_slot[BWD_BATCH];                          // emission slot of the entry: where its row goes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int tile = tile_y * gx + tile_x;
+    if (clear_word && tile == 0 && tid == 0) *clear_word = 0u;     // the per-Gaussian kernel's deferred-Gaussian counter
     // wave -> 8 rows x 16 columns, lane -> two adjacent pixels of a row
     const int px0 = tile_x * GS4D_TILE_X + 2 * (lane & 7);
     const int py = tile_y * GS4D_TILE_Y + 8 * wave + (lane >> 3);
@@ -127,10 +130,23 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     if (n_total <= 0) return;
     const int n_live = (int)min(tile_max_contrib[tile], (uint32_t)n_total);  // entries some pixel blended
 
-    float4* __restrict__ rows = reinterpret_cast<float4*>(inst_grad) + (size_t)range.x * (GS4D_GRAD_ROW / 4);
+    // A row goes to the entry's EMISSION slot (the position duplicateWithKeys gave the (Gaussian, tile) pair:
+    // offsets[id - 1] + row-major index of this tile inside the Gaussian's tile rectangle), not to its sorted
+    // position: all rows of one Gaussian are then contiguous, the per-Gaussian kernel streams them, and the inverse
+    // permutation (a kernel over all R entries plus a dependent gather per row) is not needed at all.
+    float4* __restrict__ rows = reinterpret_cast<float4*>(inst_grad);
+    auto slot_of = [&](uint32_t id, float2 xy) -> uint32_t {
+        int x0, y0, x1, y1;
+        gs4d::tile_rect(xy.x, xy.y, radii[id], gx, gy, x0, y0, x1, y1);
+        const uint32_t first = id ? point_offsets[id - 1] : 0u;
+        return first + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
+    };
     // zero-fill rows of entries nobody reached
-    for (int i = n_live * (GS4D_GRAD_ROW / 4) + tid; i < n_total * (GS4D_GRAD_ROW / 4); i += BWD_THREADS)
-        rows[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = n_live + tid; i < n_total; i += BWD_THREADS) {
+        const uint32_t id = point_list[range.x + i];
+        float4* dst = rows + (size_t)slot_of(id, means2D[id]) * (GS4D_GRAD_ROW / 4);
+        dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (n_live == 0) return;
 
     const size_t pix = (size_t)py * W + px0;
@@ -172,6 +188,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             s_b[e] = make_float4(co.z, co.w, d, r);
             s_c[e] = make_float2(g, b);
             s_box[e] = gs4d::alpha_support_box(xy, co);
+            s_slot[e] = slot_of(id, xy);
         }
         __syncthreads();
 
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
             const float Sx = sl[2], Sy = sl[6], Sxx = sl[9], Sxy = sl[7], Syy = sl[10], Sq = sl[8];
             const float mx = -o * (cx * Sx + cy * Sy), my = -o * (cz * Sy + cy * Sx);
             const float oh = -0.5f * o;
-            float4* dst = rows + (size_t)(lo + e) * (GS4D_GRAD_ROW / 4);
+            float4* dst = rows + (size_t)s_slot[e] * (GS4D_GRAD_ROW / 4);
             dst[0] = make_float4(sl[0], sl[3], sl[1], sl[4]);
             dst[1] = make_float4(mx * ddelx_dx, my * ddely_dy, oh * Sxx, oh * Sxy);
             dst[2] = make_float4(oh * Syy, Sq, 0.f, 0.f);
@@ -282,9 +299,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
 
 }  // namespace
 
-int gs4d_launch_blend_backward(int W, int H, int R, const GeomState& g, const BinningState& b, const ImageState& im,
-                               const float* features, const float* bg, const float* dL_dpix,
-                               const float* dL_dpix_depth, float* inst_grad, int debug, hipStream_t s)
+int gs4d_launch_blend_backward(int W, int H, int R, const int* radii, const GeomState& g, const BinningState& b,
+                               const ImageState& im, const float* features, const float* bg, const float* dL_dpix,
+                               const float* dL_dpix_depth, float* inst_grad, uint32_t* clear_word, int debug, hipStream_t s)
 {
     (void)R;
     GS4D_PROF("blend_backward", s);
@@ -292,7 +309,7 @@ int gs4d_launch_blend_backward(int W, int H, int R, const GeomState& g, const Bi
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
     hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3(gx, gy), dim3(BWD_THREADS), 0, s, W, H, gx, im.ranges,
                        b.point_list(), im.tile_max_contrib, bg, g.means2D, g.conic_opacity, features, g.depths,
-                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, inst_grad);
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, radii, g.point_offsets, gy, inst_grad, clear_word);
     GS4D_LAUNCH_CHECK("blend_backward", debug, s);
     return GS4D_OK;
 }

@@ -27,7 +27,7 @@ struct GeomBwdArgs {
     const float* means3D; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rotations; float scale_modifier; const float* cov3D;
     const float* view; const float* proj; float h_x, h_y, tan_fovx, tan_fovy; const float* campos;
-    const uint32_t* tiles_touched; const uint32_t* point_offsets; const uint32_t* inv; const float* inst_grad;
+    const uint32_t* tiles_touched; const uint32_t* point_offsets; const float* inst_grad;
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
     uint32_t* big_list; uint32_t* big_count;
@@ -300,16 +300,13 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
 #pragma unroll
     for (int q = 0; q < NQ; q++) r[q] = 0.0;
     const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
-    // Every step of this walk is a dependent pair of gathers (inv -> row): four steps are issued together (16 loads
-    // in flight), summed in the same order as one by one.
+    // The Gaussian's rows are contiguous (blend_backward_kernel writes a row at its emission slot): four rows are
+    // requested together, summed in the same order as one by one.
     uint32_t s = first;
     for (; s + 4 <= end; s += 4) {
-        uint32_t k[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) k[u] = A.inv[s + u];
         float4 a[4], b[4], c[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = rows[(size_t)k[u] * 3 + 0]; b[u] = rows[(size_t)k[u] * 3 + 1]; c[u] = rows[(size_t)k[u] * 3 + 2]; }
+        for (int u = 0; u < 4; u++) { a[u] = rows[(size_t)(s + u) * 3 + 0]; b[u] = rows[(size_t)(s + u) * 3 + 1]; c[u] = rows[(size_t)(s + u) * 3 + 2]; }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             r[0] += a[u].x; r[1] += a[u].y; r[2] += a[u].z; r[3] += a[u].w;
@@ -318,8 +315,7 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
         }
     }
     for (; s < end; s++) {
-        const uint32_t k = A.inv[s];
-        const float4 a = rows[(size_t)k * 3 + 0], b = rows[(size_t)k * 3 + 1], c = rows[(size_t)k * 3 + 2];
+        const float4 a = rows[(size_t)s * 3 + 0], b = rows[(size_t)s * 3 + 1], c = rows[(size_t)s * 3 + 2];
         r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
         r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
         r[8] += c.x; r[9] += c.y;
@@ -347,8 +343,7 @@ __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
         for (int q = 0; q < NQ; q++) r[q] = 0.0;
         const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
         for (uint32_t s = first + lane; s < end; s += 64) {
-            const uint32_t k = A.inv[s];
-            const float4 a = rows[(size_t)k * 3 + 0], b = rows[(size_t)k * 3 + 1], c = rows[(size_t)k * 3 + 2];
+            const float4 a = rows[(size_t)s * 3 + 0], b = rows[(size_t)s * 3 + 1], c = rows[(size_t)s * 3 + 2];
             r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
             r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
             r[8] += c.x; r[9] += c.y;
@@ -383,12 +378,12 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
     A.h_y = H / (2.0f * tan_fovy);
     A.h_x = W / (2.0f * tan_fovx);
     A.tan_fovx = tan_fovx; A.tan_fovy = tan_fovy; A.campos = campos;
-    A.tiles_touched = g.tiles_touched; A.point_offsets = g.point_offsets; A.inv = b.inv; A.inst_grad = inst_grad;
+    A.tiles_touched = g.tiles_touched; A.point_offsets = g.point_offsets; A.inst_grad = inst_grad;
     A.dL_dmean2D = dL_dmean2D; A.dL_dconic = dL_dconic; A.dL_dopacity = dL_dopacity; A.dL_dcolor = dL_dcolor;
     A.dL_ddepth = dL_ddepth; A.dL_dmean3D = dL_dmean3D; A.dL_dcov3D = dL_dcov3D; A.dL_dsh = dL_dsh;
     A.dL_dscale = dL_dscale; A.dL_drot = dL_drot;
     // deferred-Gaussian worklist lives behind the per-instance rows (see gs4d_backward_scratch_bytes)
-    // the counter was cleared by the inverse-permutation kernel at the start of the backward (api.hip)
+    // the counter was cleared by blend_backward_kernel (api.hip)
     A.big_count = gs4d_backward_big_count(inst_grad, R);
     A.big_list = (uint32_t*)((char*)A.big_count + 256);
     hipLaunchKernelGGL(geom_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, A);

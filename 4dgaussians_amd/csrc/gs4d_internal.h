@@ -83,7 +83,6 @@ struct BinningState {
     uint32_t* values_unsorted;
     uint64_t* keys_tmp[2];    // radix-sort ping-pong
     uint32_t* values_tmp[2];
-    uint32_t* inv;            // [R] sorted position of emission slot s (built with the tile ranges)
     uint32_t* hist;           // sort scratch: [256 digits][sort blocks] + [256] digit totals
     int sorted;               // which ping-pong half holds the sorted lists after `passes` passes
     uint64_t* keys_sorted() const { return keys_tmp[sorted]; }
@@ -123,10 +122,6 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
                         int debug, hipStream_t s);
-// clear_word (may be null): one device word the kernel also sets to zero -- the backward's deferred-Gaussian counter,
-// which would otherwise cost a memset node of its own in front of the per-Gaussian kernel
-int gs4d_launch_inverse_permutation(int R, int W, int H, const int* radii, const GeomState& g, BinningState& b,
-                                    uint32_t* clear_word, int debug, hipStream_t s);
 // the deferred-Gaussian counter of the backward scratch (layout: gs4d_backward_scratch_bytes)
 static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
 {
@@ -135,9 +130,11 @@ static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
 int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
                               const float* features, const float* bg, float* out_color, float* out_depth, int debug,
                               hipStream_t s);
-int gs4d_launch_blend_backward(int W, int H, int R, const GeomState& g, const BinningState& b, const ImageState& im,
-                               const float* features, const float* bg, const float* dL_dpix,
-                               const float* dL_dpix_depth, float* inst_grad, int debug, hipStream_t s);
+// clear_word (may be null): one device word the kernel also sets to zero -- the backward's deferred-Gaussian counter,
+// which would otherwise cost a memset node of its own in front of the per-Gaussian kernel
+int gs4d_launch_blend_backward(int W, int H, int R, const int* radii, const GeomState& g, const BinningState& b,
+                               const ImageState& im, const float* features, const float* bg, const float* dL_dpix,
+                               const float* dL_dpix_depth, float* inst_grad, uint32_t* clear_word, int debug, hipStream_t s);
 int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const float* means3D, const int* radii,
                               const float* shs, const float* scales, const float* rotations, float scale_modifier,
                               const float* cov3D, const float* viewmatrix, const float* projmatrix,

@@ -50,7 +50,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 FP32_PEAK_TFLOPS = 157.3   # vector / f32-MFMA peak
 
 STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "preprocess", "scan", "emit_keys", "radix_sort", "tile_ranges",
-          "blend_forward", "l1_loss_forward", "l1_loss_backward", "inverse_permutation", "blend_backward", "geom_backward",
+          "blend_forward", "l1_loss_forward", "l1_loss_backward", "blend_backward", "geom_backward",
           "activate_backward", "mlp_backward", "hexplane_backward", "weight_grads", "plane_reg_forward", "plane_reg_backward", "adamw")
 
 
