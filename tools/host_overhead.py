@@ -11,7 +11,8 @@ Dm = importlib.import_module("4dgaussians_amd.scene.deformation"); F = importlib
 dev = torch.device("cuda")
 _, _, raw = syn.make_workload("C2", P=2000)
 pc = R.GaussianParams(raw, dev)
-deform = Dm.deform_network(bench.deform_args("C2")); deform.deformation_net.set_aabb([1.3] * 3, [-1.3] * 3); deform = deform.to(dev)
+Wl = importlib.import_module("4dgaussians_amd.workload")
+deform = Dm.deform_network(Wl.deform_args("C2")); deform.deformation_net.set_aabb([1.3] * 3, [-1.3] * 3); deform = deform.to(dev)
 cam = R.Camera(syn.look_at_camera(64, 64, azimuth=0.7), dev, time=0.37)
 bg = torch.ones(3, device=dev); target = torch.rand(3, 64, 64, device=dev)
 params = list(pc.parameters()) + list(deform.parameters())
