@@ -602,7 +602,7 @@ struct PeArgs {
 // A slot is one sin/cos PAIR of one input component and frequency (one range reduction serves both columns), a raw
 // time / force column, or a zero padding column.  A workgroup owns PE_PTS consecutive points: it builds a table of the
 // slots once (component, frequency, destination columns -- the only place that divides), stages the points' twelve
-// inputs, then lane = slot and wave = point fill an LDS tile of the PE columns [oX, ldz), which leaves as float4 rows.
+// inputs, then the (point, slot) items, dealt densely to the lanes, fill an LDS tile of the PE columns [oX, ldz), which leaves as float4 rows.
 // The first version was one lane per (point, slot) with a 64-bit division by the slot count, two more by the PE
 // count per lane and 4-byte stores strided over 704-byte rows: 34 us for 45 MB at C2 whatever the sincos cost.
 #define PE_PTS 32
@@ -657,21 +657,21 @@ __global__ __launch_bounds__(256) void pe_forward_kernel(PeArgs a, const float* 
         s_in[pl][c] = c < 3 ? xyz[3 * p + c] : c < 6 ? scales[3 * p + c - 3] : c < 10 ? rots[4 * p + c - 6] : c == 10 ? time[p] : force[p];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int pl = wave; pl < npts; pl += 4) {
+    // (point, slot) items dealt densely to the lanes; item / nslot by a multiply-high (exact for these small ranges)
+    const unsigned rcp = (unsigned)((0x100000000ull + (unsigned)nslot - 1) / (unsigned)nslot);
+    for (int item = threadIdx.x; item < npts * nslot; item += 256) {
+        const int pl = (int)__umulhi((unsigned)item, rcp), j = item - pl * nslot;
         float* __restrict__ z = s_tile + pl * pitch;
-        for (int j = lane; j < nslot; j += 64) {
-            const int4 t = s_tab[j];
-            const float2 fm = s_fm[j];
-            const float x = s_in[pl][t.y];
-            if (t.x == 0) {
-                float sn, cs;
-                sincosf(x * fm.x, &sn, &cs);
-                z[t.z] = sn * fm.y;                     // x * 0.0f for a disabled input: a NaN time stays visible
-                z[t.w] = cs * fm.y;
-            } else {
-                z[t.z] = t.x == 1 ? x * fm.y : 0.f;
-            }
+        const int4 t = s_tab[j];
+        const float2 fm = s_fm[j];
+        const float x = s_in[pl][t.y];
+        if (t.x == 0) {
+            float sn, cs;
+            sincosf(x * fm.x, &sn, &cs);
+            z[t.z] = sn * fm.y;                         // x * 0.0f for a disabled input: a NaN time stays visible
+            z[t.w] = cs * fm.y;
+        } else {
+            z[t.z] = t.x == 1 ? x * fm.y : 0.f;
         }
     }
     __syncthreads();
@@ -683,8 +683,12 @@ __global__ __launch_bounds__(256) void pe_forward_kernel(PeArgs a, const float* 
     }
 }
 
-// One lane per (point, input component): 3 xyz + 3 scales + 4 rot = 10 components per point.  (Re-reading the
-// forward's sines / cosines from Z measured slower than recomputing them: 39 us vs 29 us, strided rows.)
+// Backward of the xyz / scale / rotation encodings, same shape as the forward: a workgroup loads the dZ columns
+// [oX, oT) of PE_PTS points into an LDS tile (float4 rows), one lane per (point, (component, frequency) pair) turns
+// the pair's two gradients into its contribution g_sin cos(x f) f - g_cos sin(x f) f (sines / cosines recomputed:
+// re-reading them from Z measured slower), written over the pair's sine column, and ten lanes per point add up their
+// component's frequencies.  The first version had one lane per (point, component) with a 64-bit division, loops of 10
+// and 2 frequencies side by side in a wave and 4-byte reads strided over the rows: 23 us at C2.
 __global__ __launch_bounds__(256) void pe_backward_kernel(PeArgs a, const float* __restrict__ xyz,
                                                           const float* __restrict__ scales,
                                                           const float* __restrict__ rots, const float* __restrict__ dZ,
@@ -693,30 +697,66 @@ __global__ __launch_bounds__(256) void pe_backward_kernel(PeArgs a, const float*
                                                           int apply_mask)    // 1: dZ is unmasked (fused heads): the ReLU mask of a
                                                                              // column is the sign of its recomputed sine / cosine
 {
+    extern __shared__ float s_tile[];                   // [PE_PTS][oT - oX]
+    __shared__ int4 s_tab[PE_MAX_SLOTS];                // input component, sine column, cosine column (relative to oX), -
+    __shared__ float s_fr[PE_MAX_SLOTS];
+    __shared__ float s_in[PE_PTS][10];                  // xyz 0..2 | scales 3..5 | rotations 6..9
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     // the cell histograms of the plane backward (next launch in the stream) start at zero: cleared here, by lanes this
     // launch has to spare, instead of by a memset node of its own
     for (size_t i = gid; i < (size_t)nclear; i += (size_t)gridDim.x * 256) clear[i] = 0;
-    const size_t p = gid / 10;
-    if (p >= (size_t)a.P) return;
-    const int comp = (int)(gid % 10);
-    const float* src; float* dst; int dim, npe, c0, d;
-    if (comp < 3) { src = xyz + 3 * p; dst = dxyz + 3 * p; dim = 3; npe = a.pos_pe; c0 = a.oX; d = comp; }
-    else if (comp < 6) { src = scales + 3 * p; dst = dscales + 3 * p; dim = 3; npe = a.sr_pe; c0 = a.oS; d = comp - 3; }
-    else { src = rots + 4 * p; dst = drots + 4 * p; dim = 4; npe = a.sr_pe; c0 = a.oR; d = comp - 6; }
-    const float x = src[d];
-    const float* g = dZ + p * a.ldz + c0;
-    float acc = 0.f;
-    for (int k = 0; k < npe; k++) {
-        const float fr = (float)(1 << k);
-        float sn, cs;
-        sincosf(x * fr, &sn, &cs);
-        const float gs_ = (!apply_mask || sn > 0.f) ? g[d * npe + k] : 0.f;
-        const float gc_ = (!apply_mask || cs > 0.f) ? g[dim * npe + d * npe + k] : 0.f;
-        acc += gs_ * cs * fr;
-        acc -= gc_ * sn * fr;
+    const int n_x = 3 * a.pos_pe, n_s = 3 * a.sr_pe, n_r = 4 * a.sr_pe;
+    const int npair = n_x + n_s + n_r;
+    const int pitch = a.oT - a.oX;                      // multiple of 8
+    const size_t p0 = (size_t)blockIdx.x * PE_PTS;
+    if (p0 >= (size_t)a.P) return;                      // uniform (grid rounded up)
+    const int npts = (int)min((size_t)PE_PTS, (size_t)a.P - p0);
+    for (int j0 = threadIdx.x; j0 < npair; j0 += 256) {
+        int j = j0, dim, npe, c0, base;
+        if (j < n_x) { dim = 3; npe = a.pos_pe; c0 = a.oX; base = 0; }
+        else if (j < n_x + n_s) { j -= n_x; dim = 3; npe = a.sr_pe; c0 = a.oS; base = 3; }
+        else { j -= n_x + n_s; dim = 4; npe = a.sr_pe; c0 = a.oR; base = 6; }
+        s_tab[j0] = make_int4(base + j / npe, c0 + j - a.oX, c0 + dim * npe + j - a.oX, 0);
+        s_fr[j0] = (float)(1 << (j % npe));
     }
-    dst[d] += acc;
+    for (int e = threadIdx.x; e < npts * 10; e += 256) {
+        const int pl = e / 10, c = e - pl * 10;
+        const size_t p = p0 + pl;
+        s_in[pl][c] = c < 3 ? xyz[3 * p + c] : c < 6 ? scales[3 * p + c - 3] : rots[4 * p + c - 6];
+    }
+    const int q4 = pitch >> 2;
+    float4* __restrict__ t4 = reinterpret_cast<float4*>(s_tile);
+    for (int e = threadIdx.x; e < npts * q4; e += 256) {
+        const int pl = e / q4, c = e - pl * q4;
+        t4[e] = reinterpret_cast<const float4*>(dZ + (p0 + pl) * a.ldz + a.oX)[c];
+    }
+    __syncthreads();
+    const unsigned rcp = (unsigned)((0x100000000ull + (unsigned)npair - 1) / (unsigned)npair);
+    for (int item = threadIdx.x; item < npts * npair; item += 256) {
+        const int pl = (int)__umulhi((unsigned)item, rcp), j = item - pl * npair;
+        float* __restrict__ g = s_tile + pl * pitch;
+        const int4 t = s_tab[j];
+        const float fr = s_fr[j];
+        float sn, cs;
+        sincosf(s_in[pl][t.x] * fr, &sn, &cs);
+        const float gs_ = (!apply_mask || sn > 0.f) ? g[t.y] : 0.f;
+        const float gc_ = (!apply_mask || cs > 0.f) ? g[t.z] : 0.f;
+        float acc = gs_ * cs * fr;
+        acc -= gc_ * sn * fr;
+        g[t.y] = acc;                                   // nobody else reads this pair's columns
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < npts * 10; e += 256) {
+        const int pl = e / 10, c = e - pl * 10;
+        const size_t p = p0 + pl;
+        const int npe = c < 3 ? a.pos_pe : a.sr_pe;
+        const int col = c < 3 ? c * npe : c < 6 ? (a.oS - a.oX) + (c - 3) * npe : (a.oR - a.oX) + (c - 6) * npe;
+        const float* __restrict__ g = s_tile + pl * pitch + col;
+        float acc = 0.f;
+        for (int k = 0; k < npe; k++) acc += g[k];      // same order as the per-component loop of the first version
+        float* dst = c < 3 ? dxyz + 3 * p + c : c < 6 ? dscales + 3 * p + c - 3 : drots + 4 * p + c - 6;
+        *dst += acc;
+    }
 }
 
 // ------------------------------------------------------------------ MFMA row-block GEMM
@@ -2009,8 +2049,8 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
     PeArgs pa = {P, l.ldz, l.oX, l.oS, l.oR, l.oT, l.oF, l.Kz, d->pos_pe, d->sr_pe, d->time_pe, d->force_pe,
                  d->use_time, d->use_force};
     if (do_data) {
-        const size_t threads = (size_t)P * 10;
-        hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pa, points,
+        const size_t lds = sizeof(float) * PE_PTS * (size_t)(l.oT - l.oX);
+        hipLaunchKernelGGL(pe_backward_kernel, dim3((unsigned)(((size_t)P + PE_PTS - 1) / PE_PTS)), dim3(256), lds, s, pa, points,
                            scales, rotations, dZ, dL_dpoints, dL_dscales_in, dL_drotations_in, hist,
                            d->L * HEX_SORTS * hex_bins(d).nbins, fused_heads ? 1 : 0);
         GS4D_LAUNCH_CHECK("pe_backward", 0, s);
