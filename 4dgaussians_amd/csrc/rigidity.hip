@@ -230,8 +230,9 @@ __device__ __forceinline__ float rig_diff(const float (&b)[D], const float (&a)[
     return sqrtf(s);
 }
 
+template <typename I>
 __global__ __launch_bounds__(256) void rigidity_terms_forward_kernel(size_t pairs, int k, int n, const float4* __restrict__ packed,
-                                                                     const long long* __restrict__ idx,
+                                                                     const I* __restrict__ idx,
                                                                      const float* __restrict__ dist,
                                                                      float* __restrict__ partial /* [RIGT_BLOCKS][4] */)
 {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void rigidity_terms_forward_kernel(size_t pair
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < pairs; t += (size_t)RIGT_BLOCKS * 256) {
         const size_t i = t / (size_t)k;
-        long long j = idx[t];
+        long long j = (long long)idx[t];
         if (j < 0 || j >= n) j = (long long)i;
         const float w = expf(-100.f * dist[t]);
         const RigRow a = rig_load(packed, i), b = rig_load(packed, (size_t)j);
@@ -302,8 +303,9 @@ __device__ __forceinline__ void rig_edge(const RigRow& A, const RigRow& B, float
 }
 
 // one wave per row p.  coef (device): cx = dL/dS_xyz, cl = dL/dS_long, cr = dL/dS_rot
+template <typename I>
 __global__ __launch_bounds__(256) void rigidity_terms_backward_kernel(int n, int k, const float4* __restrict__ packed,
-                                                                      const long long* __restrict__ idx,
+                                                                      const I* __restrict__ idx,
                                                                       const float* __restrict__ dist,
                                                                       const int* __restrict__ order,
                                                                       const int* __restrict__ row_start,
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(256) void rigidity_terms_backward_kernel(int n, int
     for (int c = 0; c < 14; c++) g[c] = 0.f;
     for (int s = lane; s < k; s += 64) {                         // outgoing edges p -> m: self is the tail
         const size_t t = (size_t)p * k + s;
-        const long long m = idx[t];
+        const long long m = (long long)idx[t];
         if (m < 0 || m >= n || m == p) continue;
         rig_edge(self, rig_load(packed, (size_t)m), expf(-100.f * dist[t]), cx, cl, cr, -1.f, g);
     }
@@ -350,9 +352,10 @@ __global__ __launch_bounds__(256) void rigidity_terms_backward_kernel(int n, int
 
 extern "C" size_t gs4d_rigidity_terms_scratch_bytes(void) { return sizeof(float) * 4 * RIGT_BLOCKS; }
 
-extern "C" int gs4d_rigidity_terms_forward(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
-                                           const float* rot2, const long long* idx, const float* dist, float* packed,
-                                           float* scratch, float* sums4, void* stream)
+template <typename I>
+static int rigidity_terms_forward_impl(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
+                                       const float* rot2, const I* idx, const float* dist, float* packed, float* scratch,
+                                       float* sums4, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (n < 1 || k < 1 || !vel_xyz || !vel_long || !rot1 || !rot2 || !idx || !dist || !packed || !scratch || !sums4 ||
@@ -363,16 +366,17 @@ extern "C" int gs4d_rigidity_terms_forward(int n, int k, const float* vel_xyz, c
     GS4D_PROF("rigidity_forward", s);
     hipLaunchKernelGGL(rigidity_pack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n, vel_xyz, vel_long, rot1, rot2,
                        (float4*)packed);
-    hipLaunchKernelGGL(rigidity_terms_forward_kernel, dim3(RIGT_BLOCKS), dim3(256), 0, s, (size_t)n * k, k, n,
+    hipLaunchKernelGGL(rigidity_terms_forward_kernel<I>, dim3(RIGT_BLOCKS), dim3(256), 0, s, (size_t)n * k, k, n,
                        (const float4*)packed, idx, dist, scratch);
     hipLaunchKernelGGL(rigidity_terms_sum_kernel, dim3(1), dim3(256), 0, s, scratch, sums4);
     GS4D_LAUNCH_CHECK("rigidity_terms_forward", 0, s);
     return GS4D_OK;
 }
 
-extern "C" int gs4d_rigidity_terms_backward(int n, int k, const float* packed, const long long* idx, const float* dist,
-                                            const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
-                                            float* g_vel_long, float* g_rot1, float* g_rot2, void* stream)
+template <typename I>
+static int rigidity_terms_backward_impl(int n, int k, const float* packed, const I* idx, const float* dist, const int* order,
+                                        const int* row_start, const float* coef3, float* g_vel_xyz, float* g_vel_long,
+                                        float* g_rot1, float* g_rot2, void* stream)
 {
     hipStream_t s = (hipStream_t)stream;
     if (n < 1 || k < 1 || (size_t)n * k > 0x7fffffffull || !packed || !idx || !dist || !order || !row_start || !coef3 ||
@@ -382,8 +386,38 @@ extern "C" int gs4d_rigidity_terms_backward(int n, int k, const float* packed, c
         return GS4D_EINVAL;
     }
     GS4D_PROF("rigidity_backward", s);
-    hipLaunchKernelGGL(rigidity_terms_backward_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, k, (const float4*)packed,
+    hipLaunchKernelGGL(rigidity_terms_backward_kernel<I>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, k, (const float4*)packed,
                        idx, dist, order, row_start, coef3, g_vel_xyz, g_vel_long, g_rot1, g_rot2);
     GS4D_LAUNCH_CHECK("rigidity_terms_backward", 0, s);
     return GS4D_OK;
+}
+
+extern "C" int gs4d_rigidity_terms_forward(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
+                                           const float* rot2, const long long* idx, const float* dist, float* packed,
+                                           float* scratch, float* sums4, void* stream)
+{
+    return rigidity_terms_forward_impl<long long>(n, k, vel_xyz, vel_long, rot1, rot2, idx, dist, packed, scratch, sums4, stream);
+}
+
+extern "C" int gs4d_rigidity_terms_forward_i32(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
+                                               const float* rot2, const int* idx, const float* dist, float* packed,
+                                               float* scratch, float* sums4, void* stream)
+{
+    return rigidity_terms_forward_impl<int>(n, k, vel_xyz, vel_long, rot1, rot2, idx, dist, packed, scratch, sums4, stream);
+}
+
+extern "C" int gs4d_rigidity_terms_backward(int n, int k, const float* packed, const long long* idx, const float* dist,
+                                            const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
+                                            float* g_vel_long, float* g_rot1, float* g_rot2, void* stream)
+{
+    return rigidity_terms_backward_impl<long long>(n, k, packed, idx, dist, order, row_start, coef3, g_vel_xyz, g_vel_long, g_rot1,
+                                                   g_rot2, stream);
+}
+
+extern "C" int gs4d_rigidity_terms_backward_i32(int n, int k, const float* packed, const int* idx, const float* dist,
+                                                const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
+                                                float* g_vel_long, float* g_rot1, float* g_rot2, void* stream)
+{
+    return rigidity_terms_backward_impl<int>(n, k, packed, idx, dist, order, row_start, coef3, g_vel_xyz, g_vel_long, g_rot1,
+                                             g_rot2, stream);
 }

@@ -29,10 +29,14 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
     L = _cabi.lib()
     dev = xyz.device
     m = new_xyz.shape[0]
-    idx = torch.zeros((m, nsample), dtype=torch.int32, device=dev)
-    dist2 = torch.zeros((m, nsample), dtype=torch.float32, device=dev)
     ends = [int(v) for v in offset.tolist()]
     qends = [int(v) for v in new_offset.tolist()]
+    # the query writes every (row, slot) when a batch holds at least nsample points; only short batches leave slots
+    # untouched (zero there, as the reference's zero-initialised outputs)
+    full = all(e - s_ >= int(nsample) for s_, e in zip([0] + ends[:-1], ends) if e > s_)
+    make = torch.empty if full else torch.zeros
+    idx = make((m, nsample), dtype=torch.int32, device=dev)
+    dist2 = make((m, nsample), dtype=torch.float32, device=dev)
     same = new_xyz is xyz or (new_xyz.data_ptr() == xyz.data_ptr() and new_xyz.shape == xyz.shape)
     start = qstart = 0
     for end, qend in zip(ends, qends):
@@ -54,6 +58,15 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
                 idx[qstart:qend] += start                     # the reference's indices are global (into xyz)
         start, qstart = end, qend
     return idx, torch.sqrt(dist2)
+
+
+def knn_self_i32(points, k):
+    """The render path's query: the k nearest neighbours of every row of points (n, 3) among the same rows ->
+    idx int32 (n, k) exactly as gs4d_knn_query writes it, dist float32 (n, k).  What knn() does for one batch, without
+    the offset arithmetic and the widening to int64 (two passes over the 10 M-entry lists at C2)."""
+    n = points.shape[0]
+    off = torch.tensor([n], dtype=torch.int32)
+    return knnquery(int(k), points, points, off, off)
 
 
 def knn(x, src, k, transpose=False):

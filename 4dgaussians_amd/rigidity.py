@@ -13,18 +13,19 @@ import ctypes as C
 import torch
 
 from . import _cabi
-from .pointops import knn
+from .pointops import knn, knn_self_i32
 
 
-def transpose_graph(idx: torch.Tensor):
+def transpose_graph(idx: torch.Tensor, trusted: bool = False):
     """idx (..., n, k) -> (order int32 [n*k], row_start int32 [n+1]): the pairs i*k+s sorted by their target idx[i][s]
     and where each target's pairs begin.  Built once per neighbour graph (one device sort, shared by every term of a
-    view); it turns the backward's scatter into a gather."""
+    view); it turns the backward's scatter into a gather.  trusted=True skips the range check of the indices (two
+    reductions and two host synchronisations per view): for lists that come straight out of this package's knn()."""
     n, k = idx.shape[-2], idx.shape[-1]
     if n * k >= 2 ** 31:
         raise RuntimeError("transpose_graph: n * k must stay below 2^31")
     flat = idx.reshape(-1).to(torch.int32)
-    if flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= n):
+    if not trusted and flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= n):
         raise RuntimeError("transpose_graph: neighbour index out of range")
     targets, order = torch.sort(flat)
     # where each target's run begins in the sorted list (a bincount + cumsum costs more than the sort itself)
@@ -99,7 +100,8 @@ class _RigidityTerms(torch.autograd.Function):
             r1 = r1.clone()
         if r2.data_ptr() % 16:
             r2 = r2.clone()
-        idx_ = idx.reshape(n, k).to(torch.int64).contiguous()
+        i32 = idx.dtype == torch.int32                       # the query's own type: no widening (gs4d_rigidity_terms_*_i32)
+        idx_ = idx.reshape(n, k).contiguous() if i32 else idx.reshape(n, k).to(torch.int64).contiguous()
         dist_ = f(dist).reshape(n, k)
         L = _cabi.lib()
         L.gs4d_rigidity_terms_scratch_bytes.restype = C.c_size_t
@@ -107,9 +109,9 @@ class _RigidityTerms(torch.autograd.Function):
         packed = torch.empty((n, 16), dtype=torch.float32, device=dev)
         sums = torch.empty(4, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = L.gs4d_rigidity_terms_forward(C.c_int(n), C.c_int(k), _cabi.ptr(vx), _cabi.ptr(vl), _cabi.ptr(r1), _cabi.ptr(r2),
-                                               _cabi.ptr(idx_), _cabi.ptr(dist_), _cabi.ptr(packed), _cabi.ptr(scratch),
-                                               _cabi.ptr(sums), _cabi.current_stream(dev))
+            fn = L.gs4d_rigidity_terms_forward_i32 if i32 else L.gs4d_rigidity_terms_forward
+            rc = fn(C.c_int(n), C.c_int(k), _cabi.ptr(vx), _cabi.ptr(vl), _cabi.ptr(r1), _cabi.ptr(r2), _cabi.ptr(idx_),
+                    _cabi.ptr(dist_), _cabi.ptr(packed), _cabi.ptr(scratch), _cabi.ptr(sums), _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_rigidity_terms_forward")
         ctx.save_for_backward(packed, idx_, dist_, sums)
         ctx.graph_t = graph_t
@@ -129,9 +131,10 @@ class _RigidityTerms(torch.autograd.Function):
         g_vx, g_vl = torch.empty((n, 3), device=dev), torch.empty((n, 3), device=dev)
         g_r1, g_r2 = torch.empty((n, 4), device=dev), torch.empty((n, 4), device=dev)
         with torch.cuda.device(dev):
-            rc = _cabi.lib().gs4d_rigidity_terms_backward(
-                C.c_int(n), C.c_int(k), _cabi.ptr(packed), _cabi.ptr(idx_), _cabi.ptr(dist_), _cabi.ptr(order), _cabi.ptr(row_start),
-                _cabi.ptr(coef), _cabi.ptr(g_vx), _cabi.ptr(g_vl), _cabi.ptr(g_r1), _cabi.ptr(g_r2), _cabi.current_stream(dev))
+            L = _cabi.lib()
+            fn = L.gs4d_rigidity_terms_backward_i32 if idx_.dtype == torch.int32 else L.gs4d_rigidity_terms_backward
+            rc = fn(C.c_int(n), C.c_int(k), _cabi.ptr(packed), _cabi.ptr(idx_), _cabi.ptr(dist_), _cabi.ptr(order), _cabi.ptr(row_start),
+                    _cabi.ptr(coef), _cabi.ptr(g_vx), _cabi.ptr(g_vl), _cabi.ptr(g_r1), _cabi.ptr(g_r2), _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_rigidity_terms_backward")
         return g_vx, g_vl, g_r1, g_r2, None, None, None
 
@@ -141,7 +144,7 @@ def _neighbours(means3D_final, k):
     k = min(int(k), n)
     p = means3D_final[None].contiguous().detach()
     idx, dist = knn(p, p, k)                               # renderer.py:161 / :192
-    return k, n, idx, torch.exp(-100 * dist), transpose_graph(idx)     # weight: renderer.py:162 / :193
+    return k, n, idx, torch.exp(-100 * dist), transpose_graph(idx, trusted=True)     # weight: renderer.py:162 / :193
 
 
 def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scales_final, scales_prev, scales_nxt,
@@ -165,9 +168,8 @@ def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scale
         # rotation term scales the sum of the weights
         n = means3D_final.shape[0]
         k = min(int(k), n)
-        p = means3D_final[None].contiguous().detach()
-        idx, dist = knn(p, p, k)
-        terms = _RigidityTerms.apply(vel_xyz, vel_long, rot_v1, rot_v2, idx, dist, transpose_graph(idx))
+        idx, dist = knn_self_i32(means3D_final.detach().contiguous(), k)        # int32 lists, as the query writes them
+        terms = _RigidityTerms.apply(vel_xyz, vel_long, rot_v1, rot_v2, idx, dist, transpose_graph(idx, trusted=True))
         reg["knn_xyz"], reg["knn_long"], reg["knn_rot"] = terms[0], terms[1], terms[2]
         return reg
     k, n, idx, weight, gt = _neighbours(means3D_final, k)

@@ -403,6 +403,15 @@ int gs4d_rigidity_terms_forward(int n, int k, const float* vel_xyz, const float*
 int gs4d_rigidity_terms_backward(int n, int k, const float* packed, const long long* idx, const float* dist,
                                  const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
                                  float* g_vel_long, float* g_rot1, float* g_rot2, void* stream);
+/* The same pair with the neighbour lists as int32, the type gs4d_knn_query writes them in (pointops2's knnquery returns
+ * int32 too; utils/general_utils.py:158 widens them with .long()): the render path hands the query's output over without
+ * a 40 -> 80 MB conversion per view. */
+int gs4d_rigidity_terms_forward_i32(int n, int k, const float* vel_xyz, const float* vel_long, const float* rot1,
+                                    const float* rot2, const int* idx, const float* dist, float* packed, float* scratch,
+                                    float* sums4, void* stream);
+int gs4d_rigidity_terms_backward_i32(int n, int k, const float* packed, const int* idx, const float* dist,
+                                     const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
+                                     float* g_vel_long, float* g_rot1, float* g_rot2, void* stream);
 
 #ifdef __cplusplus
 }
