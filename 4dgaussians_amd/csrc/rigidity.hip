@@ -421,3 +421,249 @@ extern "C" int gs4d_rigidity_terms_backward_i32(int n, int k, const float* packe
     return rigidity_terms_backward_impl<int>(n, k, packed, idx, dist, order, row_start, coef3, g_vel_xyz, g_vel_long, g_rot1,
                                              g_rot2, stream);
 }
+
+// ---------------------------------------------------------------- the whole temporal branch in two launches per direction
+// gaussian_renderer/renderer.py:173-203: the three second-difference terms
+//   momentum = mean |x+ + x- - 2 x|,  scales = mean_rows sum_c |s+ + s- - 2 s|,  shs = mean |h+ + h- - 2 h|
+// and the inputs of the three kNN terms (vel_xyz = (x+ - x) / 2, vel_long = x+ - x0, rot_v1 = r - r-, rot_v2 = r+ - r)
+// were ~30 elementwise launches forward and as many backward per view.  Here one kernel reads the thirteen tensors once,
+// forms the three sums and writes the kNN terms' packed records directly; the backward kernel takes the gradients of
+// the packed fields from rigidity_terms_backward_kernel and writes all thirteen input gradients.
+namespace {
+
+#define TEMP_BLOCKS_MAX 4096
+struct TemporalIn {
+    const float* xyz0; const float* m[3]; const float* s[3]; const float* h[3]; const float* r[3];   // [0] final, [1] prev, [2] next
+};
+struct TemporalGrad {
+    float* xyz0; float* m[3]; float* s[3]; float* h[3]; float* r[3];
+};
+
+__device__ __forceinline__ float sgn(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+// 16 lanes per point: lanes 0..11 one float4 of the 48 SH floats each (shf4 = 12), lane 12 the positions, 13 the scales,
+// 14 the rotations
+__global__ __launch_bounds__(256) void temporal_forward_kernel(int n, int shf4, TemporalIn in, float4* __restrict__ packed,
+                                                               float* __restrict__ partial /* [gridDim.x][3] */)
+{
+    __shared__ float s_red[4][3];
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int p = gid >> 4, sub = gid & 15;
+    float a_m = 0.f, a_s = 0.f, a_h = 0.f;
+    if (p < n) {
+        if (sub < 12) {
+            for (int q = sub; q < shf4; q += 12) {
+                const size_t o = (size_t)p * shf4 + q;
+                const float4 f = reinterpret_cast<const float4*>(in.h[0])[o], a = reinterpret_cast<const float4*>(in.h[1])[o],
+                             b = reinterpret_cast<const float4*>(in.h[2])[o];
+                a_h += fabsf(b.x + a.x - 2.f * f.x) + fabsf(b.y + a.y - 2.f * f.y) + fabsf(b.z + a.z - 2.f * f.z) + fabsf(b.w + a.w - 2.f * f.w);
+            }
+        } else if (sub == 12) {
+            float vx[3], vl[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const size_t o = (size_t)p * 3 + c;
+                const float f = in.m[0][o], a = in.m[1][o], b = in.m[2][o];
+                a_m += fabsf(b + a - 2.f * f);
+                vx[c] = (b - f) / 2.f;
+                vl[c] = b - in.xyz0[o];
+            }
+            packed[(size_t)p * 4 + 0] = make_float4(vx[0], vx[1], vx[2], vl[0]);
+            packed[(size_t)p * 4 + 1] = make_float4(vl[1], vl[2], 0.f, 0.f);
+        } else if (sub == 13) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const size_t o = (size_t)p * 3 + c;
+                a_s += fabsf(in.s[2][o] + in.s[1][o] - 2.f * in.s[0][o]);
+            }
+        } else if (sub == 14) {
+            const float4 f = reinterpret_cast<const float4*>(in.r[0])[p], a = reinterpret_cast<const float4*>(in.r[1])[p],
+                         b = reinterpret_cast<const float4*>(in.r[2])[p];
+            packed[(size_t)p * 4 + 2] = make_float4(f.x - a.x, f.y - a.y, f.z - a.z, f.w - a.w);
+            packed[(size_t)p * 4 + 3] = make_float4(b.x - f.x, b.y - f.y, b.z - f.z, b.w - f.w);
+        }
+    }
+    float v[3] = {a_m, a_s, a_h};
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        for (int off = 32; off >= 1; off >>= 1) v[q] += __shfl_xor(v[q], off, 64);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = v[q];
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+        partial[(size_t)blockIdx.x * 3 + threadIdx.x] = (s_red[0][threadIdx.x] + s_red[1][threadIdx.x]) + (s_red[2][threadIdx.x] + s_red[3][threadIdx.x]);
+}
+
+// one workgroup: the seven raw sums in fixed order (double), then the six terms of the dictionary
+//   out6 = (momentum, scales, shs, knn_xyz, knn_long, knn_rot), sums7 kept for the backward
+__global__ __launch_bounds__(256) void temporal_final_kernel(int n, int k, int shf, int nblk, const float* __restrict__ part3,
+                                                             const float* __restrict__ part4, float* __restrict__ sums7,
+                                                             float* __restrict__ out6)
+{
+    __shared__ double s[4][7];
+    double acc[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblk; b += 256)
+        for (int q = 0; q < 3; q++) acc[q] += (double)part3[(size_t)b * 3 + q];
+    for (int b = threadIdx.x; b < RIGT_BLOCKS; b += 256)
+        for (int q = 0; q < 4; q++) acc[3 + q] += (double)part4[(size_t)b * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        double v = acc[q];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t[7];
+        for (int q = 0; q < 7; q++) { t[q] = (float)((s[0][q] + s[1][q]) + (s[2][q] + s[3][q])); sums7[q] = t[q]; }
+        const float kn = (float)k * (float)n;
+        out6[0] = t[0] / (3.f * (float)n);
+        out6[1] = t[1] / (float)n;
+        out6[2] = t[2] / ((float)shf * (float)n);
+        out6[3] = t[3] / kn;
+        out6[4] = t[4] / kn;
+        out6[5] = t[5] / kn * t[6] / kn;
+    }
+}
+
+// coef6 = dL/d(raw sums) from the upstream gradient of the six terms
+__global__ void temporal_coef_kernel(int n, int k, int shf, const float* __restrict__ g6, const float* __restrict__ sums7,
+                                     float* __restrict__ coef6)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float kn = (float)k * (float)n;
+    coef6[0] = g6[3] / kn;                       // cx, cl, cr first: rigidity_terms_backward_kernel reads coef[0..2]
+    coef6[1] = g6[4] / kn;
+    coef6[2] = g6[5] * sums7[6] / kn / kn;
+    coef6[3] = g6[0] / (3.f * (float)n);
+    coef6[4] = g6[1] / (float)n;
+    coef6[5] = g6[2] / ((float)shf * (float)n);
+}
+
+__global__ __launch_bounds__(256) void temporal_backward_kernel(int n, int shf4, TemporalIn in, const float* __restrict__ coef6,
+                                                                const float* __restrict__ g_vx, const float* __restrict__ g_vl,
+                                                                const float* __restrict__ g_r1, const float* __restrict__ g_r2,
+                                                                TemporalGrad d)
+{
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    const int p = gid >> 4, sub = gid & 15;
+    if (p >= n) return;
+    const float cm = coef6[3], cs = coef6[4], ch = coef6[5];
+    if (sub < 12) {
+        for (int q = sub; q < shf4; q += 12) {
+            const size_t o = (size_t)p * shf4 + q;
+            const float4 f = reinterpret_cast<const float4*>(in.h[0])[o], a = reinterpret_cast<const float4*>(in.h[1])[o],
+                         b = reinterpret_cast<const float4*>(in.h[2])[o];
+            const float4 t = make_float4(ch * sgn(b.x + a.x - 2.f * f.x), ch * sgn(b.y + a.y - 2.f * f.y),
+                                         ch * sgn(b.z + a.z - 2.f * f.z), ch * sgn(b.w + a.w - 2.f * f.w));
+            reinterpret_cast<float4*>(d.h[0])[o] = make_float4(-2.f * t.x, -2.f * t.y, -2.f * t.z, -2.f * t.w);
+            reinterpret_cast<float4*>(d.h[1])[o] = t;
+            reinterpret_cast<float4*>(d.h[2])[o] = t;
+        }
+    } else if (sub == 12) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const size_t o = (size_t)p * 3 + c;
+            const float t = cm * sgn(in.m[2][o] + in.m[1][o] - 2.f * in.m[0][o]);
+            const float gx = g_vx[o] * 0.5f, gl = g_vl[o];
+            d.m[0][o] = -2.f * t - gx;
+            d.m[1][o] = t;
+            d.m[2][o] = t + gx + gl;
+            d.xyz0[o] = -gl;
+        }
+    } else if (sub == 13) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const size_t o = (size_t)p * 3 + c;
+            const float t = cs * sgn(in.s[2][o] + in.s[1][o] - 2.f * in.s[0][o]);
+            d.s[0][o] = -2.f * t;
+            d.s[1][o] = t;
+            d.s[2][o] = t;
+        }
+    } else if (sub == 14) {
+        const float4 a = reinterpret_cast<const float4*>(g_r1)[p], b = reinterpret_cast<const float4*>(g_r2)[p];
+        reinterpret_cast<float4*>(d.r[0])[p] = make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w);
+        reinterpret_cast<float4*>(d.r[1])[p] = make_float4(-a.x, -a.y, -a.z, -a.w);
+        reinterpret_cast<float4*>(d.r[2])[p] = b;
+    }
+}
+
+static bool temporal_ptrs_ok(const float* const* t13, int align_from)
+{
+    for (int i = 0; i < 13; i++) {
+        if (!t13[i]) return false;
+        if (i >= align_from && ((uintptr_t)t13[i] & 15)) return false;      // shs and rotations are read as float4
+    }
+    return true;
+}
+
+}  // namespace
+
+extern "C" size_t gs4d_temporal_regulation_scratch_bytes(int n)
+{
+    const size_t nblk = ((size_t)n * 16 + 255) / 256;
+    return sizeof(float) * (3 * nblk + 4 * RIGT_BLOCKS + 7 + 6 + 14 * (size_t)n) + 1024;
+}
+
+// in13: xyz0, means (final, prev, next), scales (final, prev, next: ACTIVATED), shs (final, prev, next), rotations (final
+// activated, prev, next as the deformation returns them).  out6: the six terms.  scratch: gs4d_temporal_regulation_scratch_bytes(n),
+// kept (with packed) for the backward.
+extern "C" int gs4d_temporal_regulation_forward(int n, int k, int sh_floats, const float* const* in13, const int* idx,
+                                                const float* dist, float* packed, float* scratch, float* out6, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 1 || k < 1 || sh_floats < 4 || (sh_floats & 3) || !in13 || !idx || !dist || !packed || !scratch || !out6 ||
+        ((uintptr_t)packed & 15) || ((uintptr_t)scratch & 15) || !temporal_ptrs_ok(in13, 7)) {
+        gs4d_set_error("gs4d_temporal_regulation_forward: bad sizes, null or misaligned pointer");
+        return GS4D_EINVAL;
+    }
+    TemporalIn in;
+    in.xyz0 = in13[0];
+    for (int q = 0; q < 3; q++) { in.m[q] = in13[1 + q]; in.s[q] = in13[4 + q]; in.h[q] = in13[7 + q]; in.r[q] = in13[10 + q]; }
+    const int nblk = (int)(((size_t)n * 16 + 255) / 256);
+    float* part3 = scratch;
+    float* part4 = part3 + 3 * (size_t)nblk;
+    float* sums7 = part4 + 4 * RIGT_BLOCKS;
+    GS4D_PROF("rigidity_forward", s);
+    hipLaunchKernelGGL(temporal_forward_kernel, dim3(nblk), dim3(256), 0, s, n, sh_floats / 4, in, (float4*)packed, part3);
+    hipLaunchKernelGGL(rigidity_terms_forward_kernel<int>, dim3(RIGT_BLOCKS), dim3(256), 0, s, (size_t)n * k, k, n,
+                       (const float4*)packed, idx, dist, part4);
+    hipLaunchKernelGGL(temporal_final_kernel, dim3(1), dim3(256), 0, s, n, k, sh_floats, nblk, part3, part4, sums7, out6);
+    GS4D_LAUNCH_CHECK("temporal_regulation_forward", 0, s);
+    return GS4D_OK;
+}
+
+// g6: upstream gradient of the six terms (device).  grad13: gradients of in13, written in full.
+extern "C" int gs4d_temporal_regulation_backward(int n, int k, int sh_floats, const float* const* in13, const int* idx,
+                                                 const float* dist, const int* order, const int* row_start,
+                                                 const float* packed, float* scratch, const float* g6, float* const* grad13,
+                                                 void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 1 || k < 1 || (size_t)n * k > 0x7fffffffull || sh_floats < 4 || (sh_floats & 3) || !in13 || !grad13 || !idx ||
+        !dist || !order || !row_start || !packed || !scratch || !g6 || ((uintptr_t)packed & 15) || ((uintptr_t)scratch & 15) ||
+        !temporal_ptrs_ok(in13, 7) || !temporal_ptrs_ok((const float* const*)grad13, 7)) {
+        gs4d_set_error("gs4d_temporal_regulation_backward: bad sizes, null or misaligned pointer");
+        return GS4D_EINVAL;
+    }
+    TemporalIn in;
+    TemporalGrad d;
+    in.xyz0 = in13[0]; d.xyz0 = grad13[0];
+    for (int q = 0; q < 3; q++) {
+        in.m[q] = in13[1 + q]; in.s[q] = in13[4 + q]; in.h[q] = in13[7 + q]; in.r[q] = in13[10 + q];
+        d.m[q] = grad13[1 + q]; d.s[q] = grad13[4 + q]; d.h[q] = grad13[7 + q]; d.r[q] = grad13[10 + q];
+    }
+    const int nblk = (int)(((size_t)n * 16 + 255) / 256);
+    float* sums7 = scratch + 3 * (size_t)nblk + 4 * RIGT_BLOCKS;
+    float* coef6 = sums7 + 7;
+    float* gbase = (float*)(((uintptr_t)(coef6 + 6) + 255) & ~(uintptr_t)255);     // g_r1 [n,4] | g_r2 [n,4] | g_vx [n,3] | g_vl [n,3]
+    // rotations first: 16-byte aligned for any n
+    float* g_r1 = gbase; float* g_r2 = gbase + 4 * (size_t)n; float* g_vx = gbase + 8 * (size_t)n; float* g_vl = g_vx + 3 * (size_t)n;
+    GS4D_PROF("rigidity_backward", s);
+    hipLaunchKernelGGL(temporal_coef_kernel, dim3(1), dim3(64), 0, s, n, k, sh_floats, g6, sums7, coef6);
+    hipLaunchKernelGGL(rigidity_terms_backward_kernel<int>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, n, k, (const float4*)packed,
+                       idx, dist, order, row_start, coef6, g_vx, g_vl, g_r1, g_r2);
+    hipLaunchKernelGGL(temporal_backward_kernel, dim3(nblk), dim3(256), 0, s, n, sh_floats / 4, in, coef6, g_vx, g_vl, g_r1, g_r2, d);
+    GS4D_LAUNCH_CHECK("temporal_regulation_backward", 0, s);
+    return GS4D_OK;
+}

@@ -139,6 +139,53 @@ class _RigidityTerms(torch.autograd.Function):
         return g_vx, g_vl, g_r1, g_r2, None, None, None
 
 
+class _TemporalRegulation(torch.autograd.Function):
+    """The thirteen tensors of temporal_regulation -> tensor [6] = (momentum, scales, shs, knn_xyz, knn_long, knn_rot),
+    two launches of csrc/rigidity.hip per direction (gs4d_temporal_regulation_*): the second-difference terms, the kNN
+    terms' inputs and their gradients never exist as tensors of their own."""
+
+    @staticmethod
+    def forward(ctx, k, *t13):
+        dev = t13[1].device
+        n = t13[1].shape[0]
+        f = lambda t: t.detach().to(torch.float32).contiguous()
+        ins = [f(t) for t in t13]
+        for i in range(7, 13):                               # shs and rotations are read as float4
+            if ins[i].data_ptr() % 16:
+                ins[i] = ins[i].clone()
+        shf = ins[7].numel() // n
+        idx, dist = knn_self_i32(ins[1], k)                  # neighbours of means3D_final (renderer.py:192)
+        order, row_start = transpose_graph(idx, trusted=True)
+        L = _cabi.lib()
+        L.gs4d_temporal_regulation_scratch_bytes.restype = C.c_size_t
+        scratch = torch.empty(int(L.gs4d_temporal_regulation_scratch_bytes(C.c_int(n))) // 4 + 4, dtype=torch.float32, device=dev)
+        packed = torch.empty((n, 16), dtype=torch.float32, device=dev)
+        out = torch.empty(6, dtype=torch.float32, device=dev)
+        ptrs = (C.c_void_p * 13)(*[t.data_ptr() for t in ins])
+        with torch.cuda.device(dev):
+            rc = L.gs4d_temporal_regulation_forward(C.c_int(n), C.c_int(k), C.c_int(shf), ptrs, _cabi.ptr(idx), _cabi.ptr(dist),
+                                                    _cabi.ptr(packed), _cabi.ptr(scratch), _cabi.ptr(out), _cabi.current_stream(dev))
+        _cabi.check(rc, "gs4d_temporal_regulation_forward")
+        ctx.save_for_backward(*ins, idx, dist, order, row_start, packed, scratch)
+        ctx.k, ctx.shf, ctx.shapes = k, shf, [t.shape for t in t13]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        *ins, idx, dist, order, row_start, packed, scratch = ctx.saved_tensors
+        n, dev = ins[1].shape[0], ins[1].device
+        g_ = g.to(torch.float32).contiguous()
+        grads = [torch.empty_like(t) for t in ins]
+        ip = (C.c_void_p * 13)(*[t.data_ptr() for t in ins])
+        gp = (C.c_void_p * 13)(*[t.data_ptr() for t in grads])
+        with torch.cuda.device(dev):
+            rc = _cabi.lib().gs4d_temporal_regulation_backward(
+                C.c_int(n), C.c_int(ctx.k), C.c_int(ctx.shf), ip, _cabi.ptr(idx), _cabi.ptr(dist), _cabi.ptr(order),
+                _cabi.ptr(row_start), _cabi.ptr(packed), _cabi.ptr(scratch), _cabi.ptr(g_), gp, _cabi.current_stream(dev))
+        _cabi.check(rc, "gs4d_temporal_regulation_backward")
+        return (None, *[gr.view(sh) for gr, sh in zip(grads, ctx.shapes)])
+
+
 def _neighbours(means3D_final, k):
     n = means3D_final.shape[0]
     k = min(int(k), n)
@@ -155,6 +202,13 @@ def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scale
     fused=True computes the three kNN terms with gs4d_rigidity_terms_* (one kernel per direction); fused=False composes
     them from neighbor_diff_norm and torch expressions, line by line as the reference."""
     reg = {}
+    if fused and means3D_final.device.type == "cuda":
+        n = means3D_final.shape[0]
+        out = _TemporalRegulation.apply(min(int(k), n), means3D, means3D_final, means3D_prev, means3D_nxt, scales_final, scales_prev,
+                                        scales_nxt, shs_final, shs_prev, shs_nxt, rotations_final, rotations_prev, rotations_next)
+        for i, name in enumerate(("momentum", "scales", "shs", "knn_xyz", "knn_long", "knn_rot")):
+            reg[name] = out[i]
+        return reg
     momentum_all = torch.abs(means3D_nxt + means3D_prev - 2 * means3D_final)
     reg["momentum"] = momentum_all.mean()
     reg["scales"] = torch.abs(scales_nxt + scales_prev - 2 * scales_final).sum(dim=1).mean()

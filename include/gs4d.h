@@ -413,6 +413,22 @@ int gs4d_rigidity_terms_backward_i32(int n, int k, const float* packed, const in
                                      const int* order, const int* row_start, const float* coef3, float* g_vel_xyz,
                                      float* g_vel_long, float* g_rot1, float* g_rot2, void* stream);
 
+/* The whole temporal branch of the fine stage's regulariser dictionary, gaussian_renderer/renderer.py:173-203, in two
+ * calls: forward -> out6 = (momentum, scales, shs, knn_xyz, knn_long, knn_rot) on the device; backward -> the gradients of
+ * the thirteen inputs given g6 = the upstream gradient of out6 (device).  in13 / grad13 are HOST arrays of 13 device
+ * pointers: xyz0 [n,3]; means3D final / prev / next [n,3]; scales final / prev / next [n,3] (activated, :145,:181-182);
+ * shs final / prev / next [n, sh_floats] (16-byte aligned, sh_floats a multiple of 4); rotations final (activated, :146) /
+ * prev / next [n,4] (16-byte aligned).  idx [n,k] int32 and dist [n,k]: the k nearest neighbours of means3D_final
+ * (gs4d_knn_query; dist carries no gradient); order / row_start: the transposed neighbour graph as for
+ * gs4d_rigidity_terms_backward.  packed [n][16] floats and scratch (gs4d_temporal_regulation_scratch_bytes(n), 16-byte
+ * aligned) are written by the forward and read by the backward.  Gradients are written in full, deterministic. */
+size_t gs4d_temporal_regulation_scratch_bytes(int n);
+int gs4d_temporal_regulation_forward(int n, int k, int sh_floats, const float* const* in13, const int* idx,
+                                     const float* dist, float* packed, float* scratch, float* out6, void* stream);
+int gs4d_temporal_regulation_backward(int n, int k, int sh_floats, const float* const* in13, const int* idx,
+                                      const float* dist, const int* order, const int* row_start, const float* packed,
+                                      float* scratch, const float* g6, float* const* grad13, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
