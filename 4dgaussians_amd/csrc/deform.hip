@@ -1113,7 +1113,12 @@ struct DwJob {
                                          // column Kp of a slab row holds the bias partial (column sums of G, formed while G is staged)
     float* dW; float* db;                // final destinations [N][K], [N]
 };
-struct DwJobs { DwJob j[16]; int njobs, nz, nchunks; };
+// One job may be BLOCK-DIAGONAL: the second Linears of the three small heads (3 / 3 / 4 outputs over 64 inputs each) run as
+// one job G = dO[:, 0..23] x X = H1[:, 0..191] -- six tiles in one workgroup per chunk instead of three workgroups of two
+// tiles each, every one of which paid the full per-step staging and barrier cost -- and the reduce picks head h's rows
+// [n0, n0 + n) x columns [k0, k0 + 64) out of the slab.
+struct DwSplit { int job; int n0[3], n[3], k0[3], K; float* dW[3]; float* db[3]; };   // job < 0: none
+struct DwJobs { DwJob j[16]; int njobs, nz, nchunks; DwSplit sp; };
 
 // One workgroup = one (chunk of DW_ROWS_PER_WG point rows, job, slice of <= 6 k-blocks).  The rows are staged
 // through LDS in sub-blocks of DW_RB (every element of G and X is fetched from memory exactly once per
@@ -1323,18 +1328,29 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(int nchunks, DwJobs jobs
     const int pitch = 32 * ((J.Kp + 1 + 31) >> 5);
     const int o = threadIdx.x & 63, q = threadIdx.x >> 6;          // output of the block, chunk quarter
     const int idx = blockIdx.x * 64 + o;
-    const int total = J.N * (J.K + 1);
+    const bool split = (int)blockIdx.y == jobs.sp.job;             // uniform
+    const DwSplit& S = jobs.sp;
+    const int total = split ? (S.n[0] + S.n[1] + S.n[2]) * (S.K + 1) : J.N * (J.K + 1);
     if (blockIdx.x * 64 >= total) return;                          // uniform
-    const int n = min(idx, total - 1) / (J.K + 1), k = min(idx, total - 1) % (J.K + 1);
+    int n, k, kpad = J.Kp, Kout = J.K, nout = 0, part_h = 0;       // kpad: the bias column unless k < Kout
+    if (split) {
+        int r = min(idx, total - 1) / (S.K + 1);                   // output row among the heads' rows, head after head
+        k = min(idx, total - 1) % (S.K + 1);
+        while (part_h < 2 && r >= S.n[part_h]) { r -= S.n[part_h]; part_h++; }
+        nout = r; n = S.n0[part_h] + r; Kout = S.K;
+        if (k < Kout) kpad = S.k0[part_h] + k;
+    } else {
+        n = min(idx, total - 1) / (J.K + 1); k = min(idx, total - 1) % (J.K + 1);
+        nout = n;
+        if (k < J.K) {
+            int kl = k, sg = 0;
+            kpad = 0;
+            while (sg < J.x_nseg - 1 && kl >= J.x_len[sg]) { kl -= J.x_len[sg]; kpad += pad4(J.x_len[sg]); sg++; }
+            kpad += kl;
+        }
+    }
     const int per = (nchunks + 3) / 4;
     const int cbeg = q * per, cend = min(nchunks, cbeg + per);
-    int kpad = J.Kp;                                               // the bias column
-    if (k < J.K) {
-        int kl = k, sg = 0;
-        kpad = 0;
-        while (sg < J.x_nseg - 1 && kl >= J.x_len[sg]) { kl -= J.x_len[sg]; kpad += pad4(J.x_len[sg]); sg++; }
-        kpad += kl;
-    }
     const float* __restrict__ src = J.slabs + (size_t)n * pitch + kpad;
     const size_t cstride = (size_t)64 * pitch;
     float s = 0.f;
@@ -1349,8 +1365,10 @@ __global__ __launch_bounds__(256) void dw_reduce_kernel(int nchunks, DwJobs jobs
     __syncthreads();
     if (q == 0 && idx < total) {
         const float t = ((part[0][o] + part[1][o]) + part[2][o]) + part[3][o];
-        if (k == J.K) J.db[n] += t;
-        else J.dW[(size_t)n * J.K + k] += t;
+        float* db = split ? S.db[part_h] : J.db;
+        float* dW = split ? S.dW[part_h] : J.dW;
+        if (k == Kout) db[nout] += t;
+        else dW[(size_t)nout * Kout + k] += t;
     }
 }
 
@@ -1778,6 +1796,7 @@ static void carve_scratch(char* base, const gs4d_deform_desc* d, const Layout& l
     const size_t nchunks = (P + DW_ROWS_PER_WG - 1) / DW_ROWS_PER_WG;
     int kmax = l.F > l.head_in[0] ? l.F : l.head_in[0];
     for (int h = 0; h < NHEAD; h++) kmax = l.head_in[h] > kmax ? l.head_in[h] : kmax;
+    kmax = 3 * WIDTH > kmax ? 3 * WIDTH : kmax;                        // the block-diagonal job of the small heads (DwSplit)
     const size_t pitch = (size_t)((kmax + 12 + 1 + 31) / 32) * 32;     // + the 4-column padding of up to three segments
     *slab_floats_per_job = nchunks * 64 * pitch;
     gs4d_obtain(p, *slabs, *slab_floats_per_job * (2 * NHEAD + GS4D_MAX_TRUNK));
@@ -1989,6 +2008,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
     // trunk backward: dT chain, ending in dfeat.  Every weight-gradient product of the network (trunk layers,
     // first and second Linear of each head) is collected into ONE dw_partial / dw_reduce launch pair below.
     DwJobs dj = {};
+    dj.sp.job = -1;
     int ndw = 0, kbmax = 0, nkmax = 0;
     auto add_dw = [&](const DwJob& q) {
         kbmax = q.kblocks > kbmax ? q.kblocks : kbmax;
@@ -2037,13 +2057,30 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         a.kblocks = (a.Kp + 31) / 32;
         a.slabs = slabs + slab_per_job * h; a.dW = g->head_w1[h]; a.db = g->head_b1[h];
         add_dw(a);
+        if (h < 3) continue;                 // the small heads' second Linears: one block-diagonal job, below
         DwJob b = {};
         b.G = dO; b.ldg = OUT_LD; b.gcol0 = l.head_ocol[h]; b.N = l.head_out[h];
-        if (h == 3 && fused_heads && !d->no_dshs) { b.G = dL_dshs; b.ldg = 48; b.gcol0 = 0; }   // dO's SH columns ARE the upstream gradient: not copied
+        if (fused_heads && !d->no_dshs) { b.G = dL_dshs; b.ldg = 48; b.gcol0 = 0; }   // dO's SH columns ARE the upstream gradient: not copied
         b.X = w.H1; b.ldx = NHEAD * WIDTH; b.x_nseg = 1; b.x_beg[0] = h * WIDTH; b.x_len[0] = WIDTH; b.K = WIDTH;
         b.relu_x = 1; b.Kp = WIDTH; b.kblocks = (WIDTH + 31) / 32;
         b.slabs = slabs + slab_per_job * (NHEAD + h); b.dW = g->head_w2[h]; b.db = g->head_b2[h];
         add_dw(b);
+    }
+    {
+        DwJob b = {};
+        b.G = dO; b.ldg = OUT_LD; b.gcol0 = 0; b.N = OC_R + 4;                          // columns 0..19: pos | scales | rotations
+        b.X = w.H1; b.ldx = NHEAD * WIDTH; b.x_nseg = 1; b.x_beg[0] = 0; b.x_len[0] = 3 * WIDTH; b.K = 3 * WIDTH;
+        b.relu_x = 1; b.Kp = 3 * WIDTH; b.kblocks = (3 * WIDTH + 31) / 32;
+        b.slabs = slabs + slab_per_job * NHEAD; b.dW = nullptr; b.db = nullptr;        // destinations: dj.sp
+        dj.sp.job = ndw;
+        dj.sp.K = WIDTH;
+        for (int h = 0; h < 3; h++) {
+            dj.sp.n0[h] = l.head_ocol[h]; dj.sp.n[h] = l.head_out[h]; dj.sp.k0[h] = h * WIDTH;
+            dj.sp.dW[h] = g->head_w2[h]; dj.sp.db[h] = g->head_b2[h];
+        }
+        nkmax = (3 + 3 + 4) * (WIDTH + 1) > nkmax ? (3 + 3 + 4) * (WIDTH + 1) : nkmax;
+        kbmax = b.kblocks > kbmax ? b.kblocks : kbmax;
+        dj.j[ndw++] = b;
     }
     // PE tails -> inputs (accumulates onto the pass-through gradients written by outputs_backward)
     PeArgs pa = {P, l.ldz, l.oX, l.oS, l.oR, l.oT, l.oF, l.Kz, d->pos_pe, d->sr_pe, d->time_pe, d->force_pe,
