@@ -177,6 +177,18 @@ uint32_t gs4d_sort_segment_cap()
     return v;
 }
 
+uint32_t gs4d_sort_wave_cap()
+{
+    // GS4D_SORT_WAVE_CAP (tests): lists of at most this many entries are sorted by one wave each; at most 512 (WSEG_CAP
+    // of binning.hip), 0 sends every list through the workgroup form
+    static const uint32_t v = [] {
+        const char* e = getenv("GS4D_SORT_WAVE_CAP");
+        long c = e ? atol(e) : 512;
+        return (uint32_t)(c < 0 ? 0 : (c > 512 ? 512 : c));
+    }();
+    return v;
+}
+
 // Number of ping-pong writes the sort performs: decides which half holds the sorted lists (BinningState::sorted =
 // (n - 1) & 1), for the forward that runs the sort and for the backward / state view that only re-derive the layout.
 static int sort_passes(int W, int H)

@@ -12,7 +12,28 @@
 
 using namespace gs4d;
 
+GS4D_TIMELINE_DEFINE(binning)
+
 namespace {
+
+// Lanes of the wave whose 8-bit digit equals this lane's (invalid lanes form their own group), as two 32-bit halves.
+// Per bit: one ballot, and same &= ~(ballot ^ -bit) on each half (xnor + and) -- written out because the compiler's
+// version of `bit ? m : ~m` on a 64-bit mask costs 11 instructions per bit instead of 7.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
+{
+    const uint64_t vm = __ballot(valid);
+    uint32_t lo = (uint32_t)vm, hi = (uint32_t)(vm >> 32);
+    if (!valid) { lo = ~lo; hi = ~hi; }
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const uint32_t bit = (d >> b) & 1u;
+        const uint64_t mb = __builtin_amdgcn_uicmp(bit, 0u, 33);    // v_cmp_ne_u32: the ballot itself, nothing around it
+        const uint32_t neg = 0u - bit;
+        lo &= ~((uint32_t)mb ^ neg);
+        hi &= ~((uint32_t)(mb >> 32) ^ neg);
+    }
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
 
 // ------------------------------------------------------------------ block-sum scan (1 workgroup)
 // block_offsets = exclusive scan of block_sums (bits 0..30; bit 31 is the workgroup's prefilter flag); counters[0] =
@@ -219,13 +240,7 @@ __global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_scatter_kernel(
         key[r] = valid ? keys_in[k] : ~0ull;
         val[r] = valid ? vals_in[k] : 0u;
         const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-        // lanes holding the same digit (invalid lanes form their own group via bit 8)
-        uint64_t same = __ballot(valid) ^ (valid ? 0ull : ~0ull);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            same &= ((d >> b) & 1u) ? m : ~m;
-        }
+        const uint64_t same = match_digit(d, valid);   // lanes holding the same digit
         const uint32_t before = (uint32_t)__popcll(same & lanemask_lt);
         const int leader = __ffsll((unsigned long long)same) - 1;
         uint32_t prev = 0;
@@ -331,8 +346,8 @@ struct SegShared {
     uint32_t digit_start[256];   // first slot of each digit inside the chunk (fast path) / running global base (long lists)
     uint32_t chunk_total[256];
     uint32_t wave[4];
-    uint32_t k[2][SEG_CAP];
-    uint32_t v[2][SEG_CAP];
+    uint32_t k[1][SEG_CAP];
+    uint32_t v[1][SEG_CAP];
     uint16_t rank[SEG_CAP];
 };
 
@@ -350,12 +365,7 @@ __device__ __forceinline__ void seg_rank_chunk(SegShared& S, const uint32_t* key
         const int pos = wave * 64 * rounds + r * 64 + lane;
         const bool valid = pos < n;
         const uint32_t d = valid ? (key[pos] >> shift) & 255u : 0u;
-        uint64_t same = __ballot(valid) ^ (valid ? 0ull : ~0ull);
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint64_t m = __ballot((d >> b) & 1u);
-            same &= ((d >> b) & 1u) ? m : ~m;
-        }
+        const uint64_t same = match_digit(d, valid);
         const uint32_t before = (uint32_t)__popcll(same & lanemask_lt);
         const int leader = __ffsll((unsigned long long)same) - 1;
         uint32_t prev = 0;
@@ -389,46 +399,272 @@ __device__ __forceinline__ void seg_rank_chunk(SegShared& S, const uint32_t* key
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void segment_depth_sort_kernel(const uint2* __restrict__ ranges,
+// Short lists -- most of them: a tile's list averages a few hundred entries -- are sorted by ONE wave each, four lists per
+// workgroup, with no workgroup barrier at all: the workgroup form above pays ~7 barriers per pass whatever the length of the
+// list, and its 43 KB of LDS per LIST kept only 3 lists per compute unit in flight.  Same passes and the same match-ballot
+// ranking (~1.2 instructions per key and pass; two other formulations are recorded in DESIGN.md: digit histograms by LDS
+// atomics ran into the ~0.3 lanes per clock of ds_add, and lane-owned blocks with 4-bit digits and DPP scans needed 3.5x
+// the instructions).  The wave keeps its keys, values and ranks in REGISTERS (entry r * 64 + lane in slot r, R = 2 / 4 / 8
+// slots), so LDS holds one copy of the list and the 256 digit counters: 5 KB per list of up to 512 entries.  A pass
+// whose digit is the same for every key (the sign / exponent byte of one tile's depths, nearly always) is skipped.
+#define WSEG_CAP 512               // entries a single wave sorts on its own
+struct WaveSeg {
+    uint32_t k[WSEG_CAP];
+    uint32_t v[WSEG_CAP];
+    uint32_t cnt[256];
+};
+union SegUnion {
+    SegShared wg;
+    WaveSeg wv[4];
+};
+
+// LDS traffic of one wave is executed in program order; this only keeps the compiler from moving it across
+__device__ __forceinline__ void wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// inclusive sum over the 64 lanes (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 and 31)
+__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
+{
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
+
+// begin, n (1 <= n <= 64 R) and tile are wave-uniform.  Loads are unconditional with clamped addresses (a load under a
+// branch makes the compiler wait for every load before it issues the next one).
+template <int R>
+__device__ __forceinline__ void wave_sort_list(WaveSeg& S, uint32_t begin, int n, uint32_t tile, const uint64_t* __restrict__ keys_a,
+                                               const uint32_t* __restrict__ vals_a, uint64_t* __restrict__ keys_b,
+                                               uint32_t* __restrict__ vals_b)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    uint32_t k[R], v[R], rank[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int pos = min(r * 64 + lane, n - 1);
+        k[r] = (uint32_t)keys_a[begin + pos];
+        v[r] = vals_a[begin + pos];
+    }
+    const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k[0]);
+    uint32_t diff = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) diff |= k[r] ^ key0;          // clamped duplicates of the last entry change nothing
+    uint32_t live = 0;                                        // bit p: byte p differs somewhere in the list (wave-uniform)
+#pragma unroll
+    for (int p = 0; p < 4; p++)
+        if (__ballot(((diff >> (8 * p)) & 255u) != 0u) != 0ull) live |= 1u << p;
+    uint4* c4 = reinterpret_cast<uint4*>(S.cnt);
+    for (int pass = 0; pass < 4; pass++) {
+        if (!((live >> pass) & 1u)) continue;                 // one digit for every key: the pass is the identity
+        const int shift = 8 * pass;
+        wave_sync();
+        c4[lane] = make_uint4(0u, 0u, 0u, 0u);
+        wave_sync();
+        // ranking in two sweeps: first the register-only part of every round (the nine ballots and what follows from
+        // them), then the chain through the LDS counters -- one read-modify-write per round, issued back to back -- and
+        // last the shuffles; with everything inside one loop a round cost three LDS round trips in sequence
+        uint32_t before[R], group[R];
+        int leader[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool valid = r * 64 + lane < n;
+            const uint64_t same = match_digit((k[r] >> shift) & 255u, valid);
+            before[r] = (uint32_t)__popcll(same & lanemask_lt);
+            leader[r] = __ffsll((unsigned long long)same) - 1;
+            group[r] = (uint32_t)__popcll(same);
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            rank[r] = 0u;
+            if (r * 64 + lane < n && lane == leader[r]) {
+                const uint32_t d = (k[r] >> shift) & 255u;
+                rank[r] = S.cnt[d];
+                S.cnt[d] = rank[r] + group[r];
+            }
+            wave_sync();                                      // the next round's leaders read what this one's wrote
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) rank[r] = (uint32_t)__shfl((int)rank[r], leader[r], 64) + before[r];
+        {
+            const uint4 c = c4[lane];                         // digits 4 lane .. 4 lane + 3
+            const uint32_t total = c.x + c.y + c.z + c.w;
+            const uint32_t excl = wave_inclusive_sum(total) - total;
+            c4[lane] = make_uint4(excl, excl + c.x, excl + c.x + c.y, excl + c.x + c.y + c.z);
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (r * 64 + lane < n) {
+                const uint32_t slot = S.cnt[(k[r] >> shift) & 255u] + rank[r];
+                S.k[slot] = k[r];
+                S.v[slot] = v[r];
+            }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int pos = min(r * 64 + lane, n - 1);
+            k[r] = S.k[pos];
+            v[r] = S.v[pos];
+        }
+    }
+    const uint64_t hi = (uint64_t)tile << 32;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int pos = r * 64 + lane;
+        if (pos < n) {
+            keys_b[begin + pos] = hi | (uint64_t)k[r];
+            vals_b[begin + pos] = v[r];
+        }
+    }
+}
+
+// Workgroup form for lists of up to SEG_CAP entries: the same register-resident scheme spread over four waves.  Wave w owns
+// the entries [w 64 R, (w + 1) 64 R) (R = 4 or 8 rounds of 64), ranks them against its own 256 counters (wave-private: no
+// barrier), then the counters of the four waves are combined per digit and scanned (thread = digit), and every entry goes to
+// digit_start[d] + offset of its wave + rank.  Four barriers per pass.
+template <int R>
+__device__ __forceinline__ void wg_sort_list(SegShared& S, uint32_t begin, int n, uint32_t tile, const uint64_t* __restrict__ keys_a,
+                                             const uint32_t* __restrict__ vals_a, uint64_t* __restrict__ keys_b,
+                                             uint32_t* __restrict__ vals_b)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    const int base = wave * 64 * R;
+    uint32_t* sk = S.k[0];
+    uint32_t* sv = S.v[0];
+    uint32_t k[R], v[R], rank[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int pos = min(base + r * 64 + lane, n - 1);
+        k[r] = (uint32_t)keys_a[begin + pos];
+        v[r] = vals_a[begin + pos];
+    }
+    const uint32_t key0 = (uint32_t)keys_a[begin];
+    uint32_t diff = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) diff |= k[r] ^ key0;          // clamped duplicates of the last entry change nothing
+    uint32_t live = 0;
+#pragma unroll
+    for (int p = 0; p < 4; p++) live |= __syncthreads_or((int)((diff >> (8 * p)) & 255u)) ? 1u << p : 0u;
+    uint4* c4 = reinterpret_cast<uint4*>(S.cnt[wave]);
+    for (int pass = 0; pass < 4; pass++) {
+        if (!((live >> pass) & 1u)) continue;                 // one digit for every key: the pass is the identity
+        const int shift = 8 * pass;
+        c4[lane] = make_uint4(0u, 0u, 0u, 0u);                // the wave's own counters (read by all before the last barrier)
+        uint32_t before[R], group[R];
+        int leader[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const bool valid = base + r * 64 + lane < n;
+            const uint64_t same = match_digit((k[r] >> shift) & 255u, valid);
+            before[r] = (uint32_t)__popcll(same & lanemask_lt);
+            leader[r] = __ffsll((unsigned long long)same) - 1;
+            group[r] = (uint32_t)__popcll(same);
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            rank[r] = 0u;
+            if (base + r * 64 + lane < n && lane == leader[r]) {
+                const uint32_t d = (k[r] >> shift) & 255u;
+                rank[r] = S.cnt[wave][d];
+                S.cnt[wave][d] = rank[r] + group[r];
+            }
+            wave_sync();                                      // the next round's leaders read what this one's wrote
+        }
+#pragma unroll
+        for (int r = 0; r < R; r++) rank[r] = (uint32_t)__shfl((int)rank[r], leader[r], 64) + before[r];
+        __syncthreads();
+        {
+            const uint32_t c0 = S.cnt[0][tid], c1 = S.cnt[1][tid], c2 = S.cnt[2][tid], c3 = S.cnt[3][tid];
+            S.cnt[0][tid] = 0; S.cnt[1][tid] = c0; S.cnt[2][tid] = c0 + c1; S.cnt[3][tid] = c0 + c1 + c2;
+            const uint32_t total = c0 + c1 + c2 + c3;
+            const uint32_t incl = wave_inclusive_sum(total);
+            if (lane == 63) S.wave[wave] = incl;
+            __syncthreads();
+            uint32_t wp = 0;
+            for (int w = 0; w < wave; w++) wp += S.wave[w];
+            S.digit_start[tid] = wp + incl - total;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++)
+            if (base + r * 64 + lane < n) {
+                const uint32_t d = (k[r] >> shift) & 255u;
+                const uint32_t slot = S.digit_start[d] + S.cnt[wave][d] + rank[r];
+                sk[slot] = k[r];
+                sv[slot] = v[r];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int pos = min(base + r * 64 + lane, n - 1);
+            k[r] = sk[pos];
+            v[r] = sv[pos];
+        }
+    }
+    const uint64_t hi = (uint64_t)tile << 32;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        const int pos = base + r * 64 + lane;
+        if (pos < n) {
+            keys_b[begin + pos] = hi | (uint64_t)k[r];
+            vals_b[begin + pos] = v[r];
+        }
+    }
+}
+
+// Grid: blocks [0, ntiles) take the lists LONGER than wave_cap, one workgroup per list (they start first: they are the
+// long poles); blocks [ntiles, ntiles + ceil(ntiles / 4)) take the lists of at most wave_cap entries, one wave per list.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void segment_depth_sort_kernel(const uint2* __restrict__ ranges,
                                                                  uint64_t* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
                                                                  uint64_t* __restrict__ keys_b, uint32_t* __restrict__ vals_b,
-                                                                 uint32_t cap)
+                                                                 uint32_t cap, uint32_t wave_cap, uint32_t ntiles)
 {
-    __shared__ SegShared S;
+    __shared__ SegUnion U;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef GS4D_TIMELINE
+    gs4d::TimelineScope tl(g_timeline, (int)blockIdx.x);
+#endif
+    if (blockIdx.x >= ntiles) {
+        const uint32_t t = (blockIdx.x - ntiles) * 4u + (uint32_t)wave;
+        if (t >= ntiles) return;
+        const uint2 range = ranges[t];
+        const uint32_t begin = (uint32_t)__builtin_amdgcn_readfirstlane((int)range.x);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)(range.y - range.x));
+#ifdef GS4D_TIMELINE
+        tl.n = n; tl.visits = 1;
+#endif
+        if (n == 0u || n > wave_cap) return;
+        WaveSeg& Sw = U.wv[wave];
+        if (n <= 128u) wave_sort_list<2>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
+        else if (n <= 256u) wave_sort_list<4>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
+        else wave_sort_list<8>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
+        return;
+    }
+    SegShared& S = U.wg;
     const uint32_t tile = blockIdx.x;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n <= 0) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef GS4D_TIMELINE
+    tl.n = (unsigned)max(n, 0);
+#endif
+    if (n <= 0 || (uint32_t)n <= wave_cap) return;
     const uint64_t hi = (uint64_t)tile << 32;
 
     if ((uint32_t)n <= cap) {
-        // ---- the list fits: input a -> LDS, four passes between the two LDS buffers, output b
-        const int rounds = (n + 255) >> 8;
-        for (int i = tid; i < n; i += 256) {
-            S.k[0][i] = (uint32_t)keys_a[range.x + i];
-            S.v[0][i] = vals_a[range.x + i];
-        }
-        __syncthreads();
-        for (int pass = 0; pass < 4; pass++) {
-            const int shift = 8 * pass, in = pass & 1, out = in ^ 1;
-            seg_rank_chunk(S, S.k[in], rounds, n, shift, true);
-            for (int r = 0; r < rounds; r++) {
-                const int pos = wave * 64 * rounds + r * 64 + lane;
-                if (pos < n) {
-                    const uint32_t kk = S.k[in][pos];
-                    const uint32_t d = (kk >> shift) & 255u;
-                    const uint32_t slot = S.digit_start[d] + S.cnt[wave][d] + S.rank[pos];
-                    S.k[out][slot] = kk;
-                    S.v[out][slot] = S.v[in][pos];
-                }
-            }
-            __syncthreads();
-        }
-        for (int i = tid; i < n; i += 256) {             // four passes: the result is back in buffer 0
-            keys_b[range.x + i] = hi | (uint64_t)S.k[0][i];
-            vals_b[range.x + i] = S.v[0][i];
-        }
+        // ---- the list fits (cap <= SEG_CAP = 2048)
+        if (n <= 1024) wg_sort_list<4>(S, range.x, n, tile, keys_a, vals_a, keys_b, vals_b);
+        else wg_sort_list<8>(S, range.x, n, tile, keys_a, vals_a, keys_b, vals_b);
         return;
     }
 
@@ -577,8 +813,10 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
         if (rc) return rc;
         hipLaunchKernelGGL(tile_bounds_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R,
                            b.keys_tmp[where], im.ranges);
-        hipLaunchKernelGGL(segment_depth_sort_kernel, dim3(gx * gy), dim3(256), 0, s, im.ranges, b.keys_tmp[where],
-                           b.values_tmp[where], b.keys_tmp[where ^ 1], b.values_tmp[where ^ 1], gs4d_sort_segment_cap());
+        const uint32_t nt = (uint32_t)(gx * gy), cap = gs4d_sort_segment_cap();
+        const uint32_t wave_cap = cap < gs4d_sort_wave_cap() ? cap : gs4d_sort_wave_cap();
+        hipLaunchKernelGGL(segment_depth_sort_kernel, dim3(nt + (nt + 3) / 4), dim3(256), 0, s, im.ranges, b.keys_tmp[where],
+                           b.values_tmp[where], b.keys_tmp[where ^ 1], b.values_tmp[where ^ 1], cap, wave_cap, nt);
         GS4D_LAUNCH_CHECK("segment_depth_sort", debug, s);
         where ^= 1;
     } else {

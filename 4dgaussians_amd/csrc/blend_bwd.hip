@@ -95,6 +95,8 @@ __device__ __forceinline__ float fold16(float a, float b)
 #define BWD_THREADS 128
 #define BWD_BATCH 128   // list entries staged per pass (LDS: 5 KB staging + 12 KB partials -> 9 workgroups per CU)
 
+GS4D_TIMELINE_DEFINE(blend_bwd)
+
 template <bool EXACT>
 __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const float4* __restrict__ conic_opacity, const float* __restrict__ colors, const float* __restrict__ depths,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const int* __restrict__ radii, const uint32_t* __restrict__ point_offsets,
-    int gy, float* __restrict__ inst_grad, uint32_t* __restrict__ clear_word)
+    int gy, float* __restrict__ inst_grad, uint32_t* __restrict__ clear_word, int mean_len)
 {
     __shared__ float4 s_a[BWD_BATCH];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[BWD_BATCH];   // conic.z, opacity, depth, r
@@ -115,6 +117,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_x = blockIdx.x, tile_y = blockIdx.y;
     const int tile = tile_y * gx + tile_x;
+#ifdef GS4D_TIMELINE
+    gs4d::TimelineScope tl(g_timeline, tile);
+#endif
     if (clear_word && tile == 0 && tid == 0) *clear_word = 0u;     // the per-Gaussian kernel's deferred-Gaussian counter
     // wave -> 8 rows x 16 columns, lane -> two adjacent pixels of a row
     const int px0 = tile_x * GS4D_TILE_X + 2 * (lane & 7);
@@ -127,8 +132,17 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const float ry0 = (float)(tile_y * GS4D_TILE_Y + 8 * wave), ry1 = ry0 + 7.0f;
     const uint2 range = ranges[tile];
     const int n_total = (int)(range.y - range.x);
+#ifdef GS4D_TIMELINE
+    tl.n = (unsigned)max(n_total, 0);
+#endif
     if (n_total <= 0) return;
     const int n_live = (int)min(tile_max_contrib[tile], (uint32_t)n_total);  // entries some pixel blended
+    // Every workgroup of the launch is resident within the first microseconds, so the launch lasts as long as the tile
+    // with the longest list needs for its serial walk: the waves of long lists get the higher issue priority and the
+    // short lists fill the gaps they leave.
+    if (n_live > 2 * mean_len) __builtin_amdgcn_s_setprio(3);
+    else if (2 * n_live > 3 * mean_len) __builtin_amdgcn_s_setprio(2);
+    else if (n_live > mean_len) __builtin_amdgcn_s_setprio(1);
 
     // A row goes to the entry's EMISSION slot (the position duplicateWithKeys gave the (Gaussian, tile) pair:
     // offsets[id - 1] + row-major index of this tile inside the Gaussian's tile rectangle), not to its sorted
@@ -273,6 +287,9 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
                     p[0] = t0; p[1] = t1; p[2] = t2;
                 }
                 written |= 1ull << (j & 63);
+#ifdef GS4D_TIMELINE
+                tl.visits++;
+#endif
             }
             if (lane == 0) s_mask[wave][jb] = written;
         }
@@ -299,17 +316,18 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
 
 }  // namespace
 
+
 int gs4d_launch_blend_backward(int W, int H, int R, const int* radii, const GeomState& g, const BinningState& b,
                                const ImageState& im, const float* features, const float* bg, const float* dL_dpix,
                                const float* dL_dpix_depth, float* inst_grad, uint32_t* clear_word, int debug, hipStream_t s)
 {
-    (void)R;
     GS4D_PROF("blend_backward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
     hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3(gx, gy), dim3(BWD_THREADS), 0, s, W, H, gx, im.ranges,
                        b.point_list(), im.tile_max_contrib, bg, g.means2D, g.conic_opacity, features, g.depths,
-                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, radii, g.point_offsets, gy, inst_grad, clear_word);
+                       im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, radii, g.point_offsets, gy, inst_grad, clear_word,
+                       (int)((size_t)(R > 0 ? R : 0) / (size_t)(gx * gy)));
     GS4D_LAUNCH_CHECK("blend_backward", debug, s);
     return GS4D_OK;
 }

@@ -109,6 +109,7 @@ static inline uint32_t gs4d_higher_msb(uint32_t n)
 // six-pass LSD sort; default is tile-first, see binning.hip) and the longest per-tile list sorted inside LDS
 bool gs4d_sort_tile_first();
 uint32_t gs4d_sort_segment_cap();
+uint32_t gs4d_sort_wave_cap();
 int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
                           uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
                           int debug, hipStream_t s);
@@ -143,3 +144,31 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
                               float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
                               float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
                               hipStream_t s);
+
+// ---- kernel experiments only (-DGS4D_TIMELINE, tools/build_timeline_lib.sh -> libgs4d_tl.so, tools/*_timeline.py): a
+// kernel records per workgroup its start / end on the 100 MHz clock, its placement and two counters of its choice
+#ifdef GS4D_TIMELINE
+#define GS4D_TIMELINE_DEFINE(name)                                                                                      \
+    namespace { __device__ unsigned long long g_timeline[4 * 65536]; }                                                  \
+    extern "C" __attribute__((visibility("default"))) int gs4d_debug_timeline_read_##name(void* host, size_t bytes)    \
+    {                                                                                                                   \
+        return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timeline), bytes < sizeof(g_timeline) ? bytes : sizeof(g_timeline)); \
+    }
+namespace gs4d {
+struct TimelineScope {
+    unsigned long long* buf; unsigned long long t0; int slot; unsigned visits = 0, n = 0;
+    __device__ TimelineScope(unsigned long long* b, int slot_) : buf(b), t0(wall_clock64()), slot(slot_) {}
+    __device__ ~TimelineScope()
+    {
+        if (threadIdx.x == 0 && slot < 65536) {
+            buf[4 * slot + 0] = t0;
+            buf[4 * slot + 1] = wall_clock64();
+            buf[4 * slot + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+            buf[4 * slot + 3] = ((unsigned long long)n << 32) | visits;
+        }
+    }
+};
+}
+#else
+#define GS4D_TIMELINE_DEFINE(name)
+#endif

@@ -1,6 +1,7 @@
 """The binning stage has two sort strategies (csrc/binning.hip): tile-first (default: two stable passes on the tile
-bits, then one in-LDS depth sort per tile, with a chunked global path for lists longer than the LDS capacity) and the
-six-pass LSD sort (GS4D_SORT=lsd).  All three code paths must produce the SAME sorted keys, point list, ranges,
+bits, then one in-LDS depth sort per tile -- one wave per list of at most 1024 entries, one workgroup per longer list,
+and a chunked global path for lists longer than the LDS capacity) and the
+six-pass LSD sort (GS4D_SORT=lsd).  All code paths must produce the SAME sorted keys, point list, ranges,
 n_contrib and image, bit for bit (the default path is checked against the oracle in test_gpu_rasterizer.py).  The
 strategy is read once per process, so the other two run in child processes."""
 import os
@@ -28,7 +29,9 @@ def test_sort_strategies_agree_bit_for_bit():
     here = sort_mode_child.digests()                       # this process: default strategy, lists sorted in LDS
     assert len(here) == 3
     longest = max(int(l.split()[1]) for l in here)
-    assert longest > 64                                     # so that a capacity of 64 really takes the chunked path
+    assert longest > 512                                    # all four instantiations of the wave form are used
     assert _child({"GS4D_SORT": "lsd"}) == here
     assert _child({"GS4D_SORT_SEGMENT_CAP": "64"}) == here
     assert _child({"GS4D_SORT_SEGMENT_CAP": "0"}) == here   # every list through the global path
+    assert _child({"GS4D_SORT_WAVE_CAP": "0"}) == here      # every list by a whole workgroup
+    assert _child({"GS4D_SORT_WAVE_CAP": "100"}) == here    # another split between the two forms
