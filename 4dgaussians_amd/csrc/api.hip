@@ -149,6 +149,9 @@ BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes)
     gs4d_obtain(chunk, b.values_tmp[0], R);
     gs4d_obtain(chunk, b.values_tmp[1], R);
     gs4d_obtain(chunk, b.hist, (size_t)256 * gs4d_sort_blocks(R) + 256);
+    b.seg_slots = R / 128 + 2;
+    gs4d_obtain(chunk, b.seg_owner, b.seg_slots);
+    gs4d_obtain(chunk, b.ckpt, b.seg_slots * GS4D_CKPT_FIELDS * 128);
     b.sorted = passes > 0 ? (passes - 1) & 1 : 0;
     return b;
 }
@@ -269,10 +272,11 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
                            const float* colors_precomp, const float* opacities, const float* scales,
                            float scale_modifier, const float* rotations, const float* cov3D_precomp,
                            const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                           float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug,
+                           float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
                            void* stream, int* num_rendered)
 {
     hipStream_t s = (hipStream_t)stream;
+    const int debug = debug_arg & 1;                // bit 1 (GS4D_FORWARD_ONLY): see include/gs4d.h
     if (num_rendered) *num_rendered = 0;
     if (P < 0 || width <= 0 || height <= 0 || !geom_alloc || !binning_alloc || !image_alloc) {
         gs4d_set_error("gs4d_rasterize_forward: bad sizes or missing allocator");
@@ -401,7 +405,8 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);
     if (rc) return rc;
     const float* features = colors_precomp ? colors_precomp : g.rgb;
-    return gs4d_launch_blend_forward(width, height, g, b, im, features, background, out_color, out_depth, debug, s);
+    return gs4d_launch_blend_forward(width, height, g, b, im, features, background, out_color, out_depth,
+                                     !(debug_arg & GS4D_FORWARD_ONLY), debug, s);
 }
 
 int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,

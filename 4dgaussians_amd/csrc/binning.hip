@@ -95,11 +95,15 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
     int P, int gx, int gy, const float2* __restrict__ means2D, const float* __restrict__ depths,
     const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ point_offsets,
-    uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint2* __restrict__ ranges, int ntiles)
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint2* __restrict__ ranges, int ntiles,
+    uint2* __restrict__ seg_owner, int seg_slots)
 {
-    // the tile ranges start as (0, 0) (empty tile); this launch is the first of the binning stage and has lanes to spare
+    // the tile ranges start as (0, 0) (empty tile) and the backward's segment slots as "nobody"; this launch is the first
+    // of the binning stage and has lanes to spare
     for (int t = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x; t < ntiles; t += gridDim.x * GS4D_PRE_BLOCK)
         ranges[t] = make_uint2(0u, 0u);
+    for (int t = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x; t < seg_slots; t += gridDim.x * GS4D_PRE_BLOCK)
+        seg_owner[t] = make_uint2(~0u, 0u);
     __shared__ uint32_t s_incl[GS4D_PRE_BLOCK];   // inclusive scan of counts inside the workgroup
     __shared__ uint32_t s_wave[GS4D_PRE_BLOCK / 64];
     __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
@@ -796,7 +800,7 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     GS4D_PROF("emit_keys", s);
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                        radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
-                       im.ranges, gx * gy);
+                       im.ranges, gx * gy, b.seg_owner, (int)b.seg_slots);
     GS4D_LAUNCH_CHECK("emit_keys", debug, s);
     }
 

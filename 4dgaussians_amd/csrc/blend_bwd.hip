@@ -94,6 +94,7 @@ __device__ __forceinline__ float fold16(float a, float b)
 #define NSLOT 12  // LDS slots per instance: slot = 3 * (lane >> 4) + t, see the store below
 #define BWD_THREADS 128
 #define BWD_BATCH 128   // list entries staged per pass (LDS: 5 KB staging + 12 KB partials -> 9 workgroups per CU)
+static_assert(GS4D_SEG % BWD_BATCH == 0, "a segment is a whole number of batches");
 
 GS4D_TIMELINE_DEFINE(blend_bwd)
 
@@ -104,7 +105,8 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const float4* __restrict__ conic_opacity, const float* __restrict__ colors, const float* __restrict__ depths,
     const float* __restrict__ final_Ts, const uint32_t* __restrict__ n_contrib, const float* __restrict__ dL_dpixels,
     const float* __restrict__ dL_dpixel_depths, const int* __restrict__ radii, const uint32_t* __restrict__ point_offsets,
-    int gy, float* __restrict__ inst_grad, uint32_t* __restrict__ clear_word, int mean_len)
+    int gy, float* __restrict__ inst_grad, uint32_t* __restrict__ clear_word, const float2* __restrict__ ckpt,
+    const uint2* __restrict__ seg_owner, int seg_slots)
 {
     __shared__ float4 s_a[BWD_BATCH];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[BWD_BATCH];   // conic.z, opacity, depth, r
@@ -115,12 +117,25 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     __shared__ uint32_t s_slot[BWD_BATCH];                          // emission slot of the entry: where its row goes
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_x = blockIdx.x, tile_y = blockIdx.y;
-    const int tile = tile_y * gx + tile_x;
+    // Workgroup q < seg_slots walks the segment >= 1 that owns checkpoint slot q, if any (seg_owner, written by the forward
+    // blend); workgroups seg_slots + t walk segment 0 of tile t (list positions [0, 256)): the lists are walked back to
+    // front in 256-entry segments, all at once, each from the pixel state the forward left in front of the NEXT segment.
+    // With one workgroup per tile the launch lasted as long as the longest list's serial walk (every workgroup is
+    // resident within microseconds): 204 us at C2 where the arithmetic of all tiles together needs half of that.
+    // The segment workgroups come first in the grid: they belong to the long lists.
 #ifdef GS4D_TIMELINE
-    gs4d::TimelineScope tl(g_timeline, tile);
+    gs4d::TimelineScope tl(g_timeline, (int)blockIdx.x);
 #endif
-    if (clear_word && tile == 0 && tid == 0) *clear_word = 0u;     // the per-Gaussian kernel's deferred-Gaussian counter
+    const int blk = (int)blockIdx.x;
+    int tile = blk - seg_slots, seg = 0;
+    if (tile < 0) {
+        const uint2 o = seg_owner[blk];
+        if (o.x == ~0u) return;
+        tile = (int)o.x;
+        seg = (int)o.y;
+    }
+    const int tile_x = tile % gx, tile_y = tile / gx;
+    if (clear_word && blockIdx.x == gridDim.x - 1 && tid == 0) *clear_word = 0u;     // the per-Gaussian kernel's deferred-Gaussian counter
     // wave -> 8 rows x 16 columns, lane -> two adjacent pixels of a row
     const int px0 = tile_x * GS4D_TILE_X + 2 * (lane & 7);
     const int py = tile_y * GS4D_TILE_Y + 8 * wave + (lane >> 3);
@@ -134,15 +149,12 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     const int n_total = (int)(range.y - range.x);
 #ifdef GS4D_TIMELINE
     tl.n = (unsigned)max(n_total, 0);
+#ifdef GS4D_TL_STRIDE
+    if (tile % GS4D_TL_STRIDE != 0) return;        // experiment: uncontended per-visit latency
+#endif
 #endif
     if (n_total <= 0) return;
     const int n_live = (int)min(tile_max_contrib[tile], (uint32_t)n_total);  // entries some pixel blended
-    // Every workgroup of the launch is resident within the first microseconds, so the launch lasts as long as the tile
-    // with the longest list needs for its serial walk: the waves of long lists get the higher issue priority and the
-    // short lists fill the gaps they leave.
-    if (n_live > 2 * mean_len) __builtin_amdgcn_s_setprio(3);
-    else if (2 * n_live > 3 * mean_len) __builtin_amdgcn_s_setprio(2);
-    else if (n_live > mean_len) __builtin_amdgcn_s_setprio(1);
 
     // A row goes to the entry's EMISSION slot (the position duplicateWithKeys gave the (Gaussian, tile) pair:
     // offsets[id - 1] + row-major index of this tile inside the Gaussian's tile rectangle), not to its sorted
@@ -155,13 +167,15 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
         const uint32_t first = id ? point_offsets[id - 1] : 0u;
         return first + (uint32_t)((tile_y - y0) * (x1 - x0) + (tile_x - x0));
     };
-    // zero-fill rows of entries nobody reached
-    for (int i = n_live + tid; i < n_total; i += BWD_THREADS) {
-        const uint32_t id = point_list[range.x + i];
-        float4* dst = rows + (size_t)slot_of(id, means2D[id]) * (GS4D_GRAD_ROW / 4);
-        dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (n_live == 0) return;
+    // zero-fill rows of entries nobody reached (the tile's first workgroup)
+    if (seg == 0)
+        for (int i = n_live + tid; i < n_total; i += BWD_THREADS) {
+            const uint32_t id = point_list[range.x + i];
+            float4* dst = rows + (size_t)slot_of(id, means2D[id]) * (GS4D_GRAD_ROW / 4);
+            dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    const int seg_lo = seg * GS4D_SEG, seg_hi = min(n_live, seg_lo + GS4D_SEG);
+    if (seg_hi <= seg_lo) return;
 
     const size_t pix = (size_t)py * W + px0;
     const size_t plane = (size_t)H * W;
@@ -183,13 +197,30 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     bg_dot_dpixel += bg[1] * dLp1;
     bg_dot_dpixel += bg[2] * dLp2;
     f2 acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f}, accd = {0.f, 0.f}, last_alpha = {0.f, 0.f};
+    if (seg_hi < n_live) {
+        // Not the last segment: T in front of position seg_hi is the forward's own value, and the colour / depth blended
+        // BEHIND that position (what the walk from the back would have accumulated) is what the forward still added
+        // after it, seen through that T: (final sum - sum so far) / T.  Its rounding error, ~eps |final sum| / T, enters
+        // the gradients multiplied by T again.  A pixel that had stopped before seg_hi has equal sums: exactly 0.
+        const uint32_t first = range.x / 128u, c_t = (uint32_t)(n_total - 1) / GS4D_SEG;
+        const float2* ck = ckpt + ((size_t)first + (size_t)seg) * (GS4D_CKPT_FIELDS * BWD_THREADS) + tid;
+        const float2* fin = ckpt + ((size_t)first + c_t) * (GS4D_CKPT_FIELDS * BWD_THREADS) + tid;
+        const float2 cT = ck[0], c0 = ck[1 * BWD_THREADS], c1 = ck[2 * BWD_THREADS], c2 = ck[3 * BWD_THREADS], cd = ck[4 * BWD_THREADS];
+        const float2 f0 = fin[1 * BWD_THREADS], f1 = fin[2 * BWD_THREADS], f2_ = fin[3 * BWD_THREADS], fd = fin[4 * BWD_THREADS];
+        auto behind = [](float fin_v, float ck_v, float t) { const float d = fin_v - ck_v; return d != 0.f ? d / t : 0.f; };
+        T = f2{cT.x, cT.y};
+        acc0 = f2{behind(f0.x, c0.x, cT.x), behind(f0.y, c0.y, cT.y)};
+        acc1 = f2{behind(f1.x, c1.x, cT.x), behind(f1.y, c1.y, cT.y)};
+        acc2 = f2{behind(f2_.x, c2.x, cT.x), behind(f2_.y, c2.y, cT.y)};
+        accd = f2{behind(fd.x, cd.x, cT.x), behind(fd.y, cd.y, cT.y)};
+    }
     float lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;   // colour / depth of the previous evaluated entry (wave-uniform)
     const float ddelx_dx = (float)(0.5 * W);
     const float ddely_dy = (float)(0.5 * H);
 
-    // batches walk the live part of the list from the back; each covers positions [lo, lo + n)
-    for (int hi = n_live; hi > 0; hi -= BWD_BATCH) {
-        const int lo = max(0, hi - BWD_BATCH);
+    // batches walk the segment from the back; each covers positions [lo, lo + n)
+    for (int hi = seg_hi; hi > seg_lo; hi -= BWD_BATCH) {
+        const int lo = max(seg_lo, hi - BWD_BATCH);
         const int n = hi - lo;
         __syncthreads();  // previous batch's rows have been flushed
         for (int e = tid; e < n; e += BWD_THREADS) {
@@ -324,10 +355,12 @@ int gs4d_launch_blend_backward(int W, int H, int R, const int* radii, const Geom
     GS4D_PROF("blend_backward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
-    hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3(gx, gy), dim3(BWD_THREADS), 0, s, W, H, gx, im.ranges,
+    (void)R;
+    hipLaunchKernelGGL(exact ? blend_backward_kernel<true> : blend_backward_kernel<false>, dim3((unsigned)(gx * gy + (int)b.seg_slots)),
+                       dim3(BWD_THREADS), 0, s, W, H, gx, im.ranges,
                        b.point_list(), im.tile_max_contrib, bg, g.means2D, g.conic_opacity, features, g.depths,
                        im.final_T, im.n_contrib, dL_dpix, dL_dpix_depth, radii, g.point_offsets, gy, inst_grad, clear_word,
-                       (int)((size_t)(R > 0 ? R : 0) / (size_t)(gx * gy)));
+                       b.ckpt, b.seg_owner, (int)b.seg_slots);
     GS4D_LAUNCH_CHECK("blend_backward", debug, s);
     return GS4D_OK;
 }

@@ -24,6 +24,8 @@
 #include "gs4d_internal.h"
 #include "gs4d_math.h"
 
+GS4D_TIMELINE_DEFINE(blend_fwd)
+
 namespace {
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -36,14 +38,18 @@ __device__ __forceinline__ float fast_exp(float x)
 }
 
 #define FWD_THREADS 128
+static_assert(GS4D_SEG == GS4D_TILE_PIX, "checkpoints are taken in front of the batches");
 
-template <bool EXACT>
+// CKPT: leave the segment checkpoints the backward walks from (BinningState::ckpt / seg_owner, gs4d_internal.h): the
+// state of every pixel in front of list positions 256, 512, ... of the tile (= in front of every batch but the first),
+// the final colour / depth sums, and one owner record per segment >= 1 that some pixel reached.
+template <bool EXACT, bool CKPT>
 __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     int W, int H, int gx, const uint2* __restrict__ ranges, const uint32_t* __restrict__ point_list,
     const float2* __restrict__ means2D, const float* __restrict__ features, const float* __restrict__ depths,
     const float4* __restrict__ conic_opacity, const float* __restrict__ bg, float* __restrict__ final_T,
     uint32_t* __restrict__ n_contrib, uint32_t* __restrict__ tile_max_contrib, float* __restrict__ out_color,
-    float* __restrict__ out_depth)
+    float* __restrict__ out_depth, float2* __restrict__ ckpt, uint2* __restrict__ seg_owner)
 {
     __shared__ float4 s_a[GS4D_TILE_PIX];   // x, y, conic.x, conic.y
     __shared__ float4 s_b[GS4D_TILE_PIX];   // conic.z, opacity, depth, r
@@ -66,6 +72,10 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
 
     const uint2 range = ranges[tile_y * gx + tile_x];
     const int n_total = (int)(range.y - range.x);
+#ifdef GS4D_TIMELINE
+    gs4d::TimelineScope tl(g_timeline, tile_y * gx + tile_x);
+    tl.n = (unsigned)max(n_total, 0);
+#endif
 
     bool done0 = !in0, done1 = !in1;
     f2 T = {1.0f, 1.0f};
@@ -78,6 +88,14 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
         if (lane == 0) s_wave_done[wave] = wave_done;
         __syncthreads();
         if (s_wave_done[0] & s_wave_done[1]) break;
+        if (CKPT && base != 0) {
+            float2* c = ckpt + ((size_t)(range.x / 128u) + (size_t)(base / GS4D_SEG) - 1u) * (GS4D_CKPT_FIELDS * FWD_THREADS) + tid;
+            c[0 * FWD_THREADS] = make_float2(T.x, T.y);
+            c[1 * FWD_THREADS] = make_float2(C0.x, C0.y);
+            c[2 * FWD_THREADS] = make_float2(C1.x, C1.y);
+            c[3 * FWD_THREADS] = make_float2(C2.x, C2.y);
+            c[4 * FWD_THREADS] = make_float2(Dp.x, Dp.y);
+        }
 
         const int n = min(GS4D_TILE_PIX, n_total - base);
         for (int e = tid; e < n; e += FWD_THREADS) {
@@ -149,6 +167,9 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                         last1 = use1 ? (uint32_t)(base + j + 1) : last1;
                     }
                     if (__ballot(!done0 || !done1) == 0ull) all_done = true;  // every pixel of this wave is finished
+#ifdef GS4D_TIMELINE
+                    tl.visits++;
+#endif
                 }
             }
         }
@@ -179,21 +200,34 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_down(m, off, 64));
     if (lane == 0) s_wave_max[wave] = m;
     __syncthreads();
-    if (tid == 0) tile_max_contrib[tile_y * gx + tile_x] = max(s_wave_max[0], s_wave_max[1]);
+    const uint32_t n_live = max(s_wave_max[0], s_wave_max[1]);
+    if (tid == 0) tile_max_contrib[tile_y * gx + tile_x] = n_live;
+    if (CKPT && n_total > GS4D_SEG) {
+        const uint32_t first = range.x / 128u, c_t = (uint32_t)(n_total - 1) / GS4D_SEG;
+        float2* c = ckpt + ((size_t)first + c_t) * (GS4D_CKPT_FIELDS * FWD_THREADS) + tid;      // the final record
+        c[1 * FWD_THREADS] = make_float2(C0.x, C0.y);
+        c[2 * FWD_THREADS] = make_float2(C1.x, C1.y);
+        c[3 * FWD_THREADS] = make_float2(C2.x, C2.y);
+        c[4 * FWD_THREADS] = make_float2(Dp.x, Dp.y);
+        for (uint32_t j = 1 + tid; j <= c_t; j += FWD_THREADS)
+            if (j * GS4D_SEG < n_live) seg_owner[first + j - 1] = make_uint2((uint32_t)(tile_y * gx + tile_x), j);
+    }
 }
 
 }  // namespace
 
 int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
-                              const float* features, const float* bg, float* out_color, float* out_depth, int debug,
-                              hipStream_t s)
+                              const float* features, const float* bg, float* out_color, float* out_depth, int checkpoints,
+                              int debug, hipStream_t s)
 {
     GS4D_PROF("blend_forward", s);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     static const bool exact = getenv("GS4D_EXACT_EXP") != nullptr;  // diagnostic switch: libm-accurate exp
-    hipLaunchKernelGGL(exact ? blend_forward_kernel<true> : blend_forward_kernel<false>, dim3(gx, gy), dim3(FWD_THREADS), 0, s, W, H, gx, im.ranges,
+    auto kernel = exact ? (checkpoints ? blend_forward_kernel<true, true> : blend_forward_kernel<true, false>)
+                        : (checkpoints ? blend_forward_kernel<false, true> : blend_forward_kernel<false, false>);
+    hipLaunchKernelGGL(kernel, dim3(gx, gy), dim3(FWD_THREADS), 0, s, W, H, gx, im.ranges,
                        b.point_list(), g.means2D, features, g.depths, g.conic_opacity, bg, im.final_T, im.n_contrib,
-                       im.tile_max_contrib, out_color, out_depth);
+                       im.tile_max_contrib, out_color, out_depth, b.ckpt, b.seg_owner);
     GS4D_LAUNCH_CHECK("blend_forward", debug, s);
     return GS4D_OK;
 }

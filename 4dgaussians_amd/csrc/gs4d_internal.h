@@ -10,6 +10,8 @@
 #define GS4D_TILE_PIX (GS4D_TILE_X * GS4D_TILE_Y)
 #define GS4D_PRE_BLOCK 256          // Gaussians per preprocess / emit workgroup
 #define GS4D_GRAD_ROW 12            // floats per per-instance gradient row (10 used, padded to 48 B)
+#define GS4D_SEG 256                // list entries per backward segment (= the forward blend's batch)
+#define GS4D_CKPT_FIELDS 5
 
 void gs4d_set_error(const char* fmt, ...);
 
@@ -84,6 +86,13 @@ struct BinningState {
     uint64_t* keys_tmp[2];    // radix-sort ping-pong
     uint32_t* values_tmp[2];
     uint32_t* hist;           // sort scratch: [256 digits][sort blocks] + [256] digit totals
+    // Segment checkpoints of the blend (blend_fwd.hip / blend_bwd.hip): the forward leaves every pixel's state in front
+    // of list positions 256, 512, ... of its tile, so that the backward can walk the 256-entry segments of a long list
+    // in parallel.  A tile whose list starts at x and has n > 256 entries owns the slots x / 128 .. x / 128 + (n - 1) / 256
+    // (checkpoints 1 .. c, then the final colour / depth record): no two tiles share a slot, nothing is counted.
+    float2* ckpt;             // [seg_slots][GS4D_CKPT_FIELDS][128 lanes]: T, C0, C1, C2, depth of the lane's two pixels
+    uint2* seg_owner;         // [seg_slots] (tile, segment >= 1) whose backward workgroup this slot is; x = ~0u: none
+    size_t seg_slots;         // R / 128 + 2
     int sorted;               // which ping-pong half holds the sorted lists after `passes` passes
     uint64_t* keys_sorted() const { return keys_tmp[sorted]; }
     uint32_t* point_list() const { return values_tmp[sorted]; }
@@ -129,8 +138,8 @@ static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
     return (uint32_t*)((char*)inst_grad + gs4d_align_up((size_t)R * GS4D_GRAD_ROW * sizeof(float), 256));
 }
 int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
-                              const float* features, const float* bg, float* out_color, float* out_depth, int debug,
-                              hipStream_t s);
+                              const float* features, const float* bg, float* out_color, float* out_depth, int checkpoints,
+                              int debug, hipStream_t s);
 // clear_word (may be null): one device word the kernel also sets to zero -- the backward's deferred-Gaussian counter,
 // which would otherwise cost a memset node of its own in front of the per-Gaussian kernel
 int gs4d_launch_blend_backward(int W, int H, int R, const int* radii, const GeomState& g, const BinningState& b,
@@ -157,13 +166,20 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
 namespace gs4d {
 struct TimelineScope {
     unsigned long long* buf; unsigned long long t0; int slot; unsigned visits = 0, n = 0;
+#ifdef GS4D_TL_CLOCK
+    unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
     __device__ TimelineScope(unsigned long long* b, int slot_) : buf(b), t0(wall_clock64()), slot(slot_) {}
     __device__ ~TimelineScope()
     {
         if (threadIdx.x == 0 && slot < 65536) {
             buf[4 * slot + 0] = t0;
             buf[4 * slot + 1] = wall_clock64();
+#ifdef GS4D_TL_CLOCK
+            buf[4 * slot + 2] = __builtin_amdgcn_s_memtime() - c0;      // shader-clock cycles instead of the placement
+#else
             buf[4 * slot + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+#endif
             buf[4 * slot + 3] = ((unsigned long long)n << 32) | visits;
         }
     }

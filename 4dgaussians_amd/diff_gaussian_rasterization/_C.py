@@ -29,8 +29,11 @@ def _dev_f32(t: torch.Tensor, device) -> torch.Tensor:
 
 def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                         viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
-                        prefiltered, debug):
-    """RasterizeGaussiansCUDA, RAST/rasterize_points.cu:35-117."""
+                        prefiltered, debug, forward_only=False):
+    """RasterizeGaussiansCUDA, RAST/rasterize_points.cu:35-117.
+
+    forward_only (no reference counterpart): the returned state will not be handed to rasterize_gaussians_backward, so
+    the blend leaves no segment checkpoints for it (GS4D_FORWARD_ONLY, include/gs4d.h)."""
     if means3D.ndimension() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     L = _cabi.lib()
@@ -61,8 +64,8 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
                 _cabi.ptr(means_), _cabi.ptr(sh_), _cabi.ptr(col_), _cabi.ptr(op_), _cabi.ptr(sc_),
                 C.c_float(scale_modifier), _cabi.ptr(rot_), _cabi.ptr(cov_), _cabi.ptr(view_), _cabi.ptr(proj_),
                 _cabi.ptr(cam_), C.c_float(tan_fovx), C.c_float(tan_fovy), C.c_int(int(bool(prefiltered))),
-                _cabi.ptr(out_color), _cabi.ptr(out_depth), _cabi.ptr(radii), C.c_int(int(bool(debug))),
-                _cabi.current_stream(device), C.byref(rendered))
+                _cabi.ptr(out_color), _cabi.ptr(out_depth), _cabi.ptr(radii),
+                C.c_int(int(bool(debug)) | (2 if forward_only else 0)), _cabi.current_stream(device), C.byref(rendered))
         for a in (geom, binning, img):
             a.close()
         _cabi.check(rc, "rasterize_gaussians")
@@ -70,6 +73,10 @@ def rasterize_gaussians(background, means3D, colors, opacity, scales, rotations,
         for a in (geom, binning, img):
             a.close()
     return rendered.value, out_color, out_depth, radii, geom.tensor, binning.tensor, img.tensor
+
+
+def rasterize_gaussians_forward_only(*args):
+    return rasterize_gaussians(*args, forward_only=True)
 
 
 def rasterize_gaussians_backward(background, means3D, radii, colors, scales, rotations, scale_modifier,

@@ -58,8 +58,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         args = (s.bg, means3D, colors_precomp, opacities, scales, rotations, s.scale_modifier, cov3Ds_precomp,
                 s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, s.image_height, s.image_width, sh, s.sh_degree,
                 s.campos, s.prefiltered, s.debug)
+        # no input asks for a gradient (render_for_image, evaluation): the blend need not leave the backward's checkpoints
+        fn = _C.rasterize_gaussians if any(ctx.needs_input_grad) else _C.rasterize_gaussians_forward_only
         num_rendered, color, depth, radii, geomBuffer, binningBuffer, imgBuffer = _call_with_snapshot(
-            _C.rasterize_gaussians, args, s.debug, "snapshot_fw.dump",
+            fn, args, s.debug, "snapshot_fw.dump",
             "\nAn error occured in forward. Please forward snapshot_fw.dump for debugging.")
         ctx.raster_settings = s
         ctx.num_rendered = num_rendered

@@ -72,7 +72,13 @@ int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
  * *num_rendered receives the number of (Gaussian, tile) instances.  One host
  * wait on `stream` happens inside (to size the binning buffer), as in
  * rasterizer_impl.cu:282; see gs4d_thread_state_release() below for how it is done.
+ * `debug`: bit 0 as in the reference (synchronise and check after every launch); bit 1
+ * (GS4D_FORWARD_ONLY, no reference counterpart) promises that the buffers of this call will not be
+ * handed to gs4d_rasterize_backward: the blend then leaves out the per-segment pixel checkpoints
+ * (20 bytes per pixel and 256 list entries) from which the backward walks a long tile list in parallel.
+ * A backward on buffers of such a call reads undefined checkpoints for tiles with more than 256 entries.
  */
+#define GS4D_FORWARD_ONLY 2
 int gs4d_rasterize_forward(
     gs4d_alloc_fn geom_alloc, void* geom_ctx,
     gs4d_alloc_fn binning_alloc, void* binning_ctx,

@@ -40,6 +40,9 @@ rd.argtypes = [C.c_void_p, C.c_size_t]
 rc = rd(buf.ctypes.data, buf.nbytes)
 assert rc == 0, rc
 b = buf[:min(T, 65536)]
+if which == "blend_bwd":           # every block of the last launch (segment slots + tiles) has a recent start time
+    b = buf[buf[:, 0] > buf[:, 0].max() - np.uint64(100000)]
+    T = b.shape[0]
 t0 = b[:, 0].astype(np.int64); t1 = b[:, 1].astype(np.int64)
 hw = (b[:, 2] & np.uint64(0xffffffff)).astype(np.int64); xcc = (b[:, 2] >> np.uint64(32)).astype(np.int64) & 0xf
 n = (b[:, 3] >> np.uint64(32)).astype(np.int64); visits = (b[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
@@ -72,6 +75,9 @@ print(f"compute units seen {uk.size}; workgroups per CU min {cnt.min()} max {cnt
 print(f"visits per CU (wave 0): min {vis.min()} p50 {int(np.median(vis))} max {vis.max()}")
 o = np.argsort(-dur)[:8]
 print("longest workgroups: " + "  ".join(f"tile {i} n {n[i]} v {visits[i]} {s_us[i]:.0f}->{e_us[i]:.0f}" for i in o))
+if os.environ.get("TL_CLOCK"):
+    cyc = b[:, 2].astype(np.float64); long = dur > 20
+    print(f"s_memtime ticks per us over workgroups longer than 20 us: median {np.median(cyc[long] / dur[long]):.1f} (min {(cyc[long] / dur[long]).min():.1f}, max {(cyc[long] / dur[long]).max():.1f})")
 # time per visit as a function of when it ran
 late = e_us > 0.6 * span
 print(f"us per visit: all {dur.sum() / max(visits.sum(), 1):.3f}; workgroups ending after 60% of the span {dur[late].sum() / max(visits[late].sum(), 1):.3f} ({late.sum()} workgroups)")
