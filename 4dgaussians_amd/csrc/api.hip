@@ -149,7 +149,7 @@ BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes)
     gs4d_obtain(chunk, b.values_tmp[0], R);
     gs4d_obtain(chunk, b.values_tmp[1], R);
     gs4d_obtain(chunk, b.hist, (size_t)256 * gs4d_sort_blocks(R) + 256);
-    b.seg_slots = R / 128 + 2;
+    b.seg_slots = R / GS4D_SEG_SLOT_DIV + 2;
     gs4d_obtain(chunk, b.seg_owner, b.seg_slots);
     gs4d_obtain(chunk, b.ckpt, b.seg_slots * GS4D_CKPT_FIELDS * 128);
     b.sorted = passes > 0 ? (passes - 1) & 1 : 0;

@@ -118,10 +118,11 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // Workgroup q < seg_slots walks the segment >= 1 that owns checkpoint slot q, if any (seg_owner, written by the forward
-    // blend); workgroups seg_slots + t walk segment 0 of tile t (list positions [0, 256)): the lists are walked back to
-    // front in 256-entry segments, all at once, each from the pixel state the forward left in front of the NEXT segment.
-    // With one workgroup per tile the launch lasted as long as the longest list's serial walk (every workgroup is
-    // resident within microseconds): 204 us at C2 where the arithmetic of all tiles together needs half of that.
+    // blend); workgroups seg_slots + t walk segment 0 of tile t (list positions [0, GS4D_SEG)): the lists are walked back
+    // to front in GS4D_SEG-entry segments, all at once, each from the pixel state the forward left in front of the NEXT
+    // segment.  With one workgroup per tile the launch lasted as long as the longest list's serial walk (every workgroup
+    // is resident within microseconds): 204 us at C2 where the arithmetic of all tiles together needs half of that;
+    // 256-entry segments 162 us, 128-entry segments 151 us (what is left of the tail is one segment's walk).
     // The segment workgroups come first in the grid: they belong to the long lists.
 #ifdef GS4D_TIMELINE
     gs4d::TimelineScope tl(g_timeline, (int)blockIdx.x);
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
         // BEHIND that position (what the walk from the back would have accumulated) is what the forward still added
         // after it, seen through that T: (final sum - sum so far) / T.  Its rounding error, ~eps |final sum| / T, enters
         // the gradients multiplied by T again.  A pixel that had stopped before seg_hi has equal sums: exactly 0.
-        const uint32_t first = range.x / 128u, c_t = (uint32_t)(n_total - 1) / GS4D_SEG;
+        const uint32_t first = range.x / (uint32_t)GS4D_SEG_SLOT_DIV, c_t = (uint32_t)(n_total - 1) / GS4D_SEG;
         const float2* ck = ckpt + ((size_t)first + (size_t)seg) * (GS4D_CKPT_FIELDS * BWD_THREADS) + tid;
         const float2* fin = ckpt + ((size_t)first + c_t) * (GS4D_CKPT_FIELDS * BWD_THREADS) + tid;
         const float2 cT = ck[0], c0 = ck[1 * BWD_THREADS], c1 = ck[2 * BWD_THREADS], c2 = ck[3 * BWD_THREADS], cd = ck[4 * BWD_THREADS];

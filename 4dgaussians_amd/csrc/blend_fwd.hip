@@ -38,10 +38,11 @@ __device__ __forceinline__ float fast_exp(float x)
 }
 
 #define FWD_THREADS 128
-static_assert(GS4D_SEG == GS4D_TILE_PIX, "checkpoints are taken in front of the batches");
+static_assert(GS4D_SEG == GS4D_TILE_PIX || 2 * GS4D_SEG == GS4D_TILE_PIX, "checkpoints are taken in front of the batches and, with 128-entry segments, in their middle");
 
 // CKPT: leave the segment checkpoints the backward walks from (BinningState::ckpt / seg_owner, gs4d_internal.h): the
-// state of every pixel in front of list positions 256, 512, ... of the tile (= in front of every batch but the first),
+// state of every pixel in front of list positions GS4D_SEG, 2 GS4D_SEG, ... of the tile (in front of every batch but the
+// first and, with 128-entry segments, in the middle of every batch),
 // the final colour / depth sums, and one owner record per segment >= 1 that some pixel reached.
 template <bool EXACT, bool CKPT>
 __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
@@ -88,14 +89,20 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
         if (lane == 0) s_wave_done[wave] = wave_done;
         __syncthreads();
         if (s_wave_done[0] & s_wave_done[1]) break;
-        if (CKPT && base != 0) {
-            float2* c = ckpt + ((size_t)(range.x / 128u) + (size_t)(base / GS4D_SEG) - 1u) * (GS4D_CKPT_FIELDS * FWD_THREADS) + tid;
+        // checkpoint j = the state in front of list position j * GS4D_SEG
+        auto checkpoint = [&](int j) {
+            float2* c = ckpt + ((size_t)(range.x / (uint32_t)GS4D_SEG_SLOT_DIV) + (size_t)j - 1u) * (GS4D_CKPT_FIELDS * FWD_THREADS) + tid;
             c[0 * FWD_THREADS] = make_float2(T.x, T.y);
             c[1 * FWD_THREADS] = make_float2(C0.x, C0.y);
             c[2 * FWD_THREADS] = make_float2(C1.x, C1.y);
             c[3 * FWD_THREADS] = make_float2(C2.x, C2.y);
             c[4 * FWD_THREADS] = make_float2(Dp.x, Dp.y);
-        }
+        };
+        if (CKPT && base != 0) checkpoint(base / GS4D_SEG);
+        // with 128-entry segments there is one more in the middle of the batch: a wave that walks the batch takes it
+        // between the second and the third 64-entry group, a wave whose pixels are all finished right away (same state)
+        const bool mid_ckpt = CKPT && GS4D_SEG < GS4D_TILE_PIX && n_total - base > GS4D_SEG;
+        if (mid_ckpt && wave_done) checkpoint(base / GS4D_SEG + 1);
 
         const int n = min(GS4D_TILE_PIX, n_total - base);
         for (int e = tid; e < n; e += FWD_THREADS) {
@@ -134,6 +141,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
             bool all_done = false;
 #pragma unroll
             for (int k = 0; k < GS4D_TILE_PIX / 64; k++) {
+                if (mid_ckpt && 64 * k == GS4D_SEG) checkpoint(base / GS4D_SEG + 1);
                 unsigned long long m = hits[k];
                 while (m != 0ull && !all_done) {
                     const int j = 64 * k + __builtin_ctzll(m);
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
     const uint32_t n_live = max(s_wave_max[0], s_wave_max[1]);
     if (tid == 0) tile_max_contrib[tile_y * gx + tile_x] = n_live;
     if (CKPT && n_total > GS4D_SEG) {
-        const uint32_t first = range.x / 128u, c_t = (uint32_t)(n_total - 1) / GS4D_SEG;
+        const uint32_t first = range.x / (uint32_t)GS4D_SEG_SLOT_DIV, c_t = (uint32_t)(n_total - 1) / GS4D_SEG;
         float2* c = ckpt + ((size_t)first + c_t) * (GS4D_CKPT_FIELDS * FWD_THREADS) + tid;      // the final record
         c[1 * FWD_THREADS] = make_float2(C0.x, C0.y);
         c[2 * FWD_THREADS] = make_float2(C1.x, C1.y);

@@ -10,7 +10,10 @@
 #define GS4D_TILE_PIX (GS4D_TILE_X * GS4D_TILE_Y)
 #define GS4D_PRE_BLOCK 256          // Gaussians per preprocess / emit workgroup
 #define GS4D_GRAD_ROW 12            // floats per per-instance gradient row (10 used, padded to 48 B)
-#define GS4D_SEG 256                // list entries per backward segment (= the forward blend's batch)
+#ifndef GS4D_SEG
+#define GS4D_SEG 128                // list entries per backward segment: 128 or 256 (half of / the forward blend's batch)
+#endif
+#define GS4D_SEG_SLOT_DIV (GS4D_SEG / 2)   // a tile whose list starts at x owns checkpoint slots from x / GS4D_SEG_SLOT_DIV
 #define GS4D_CKPT_FIELDS 5
 
 void gs4d_set_error(const char* fmt, ...);
@@ -87,12 +90,12 @@ struct BinningState {
     uint32_t* values_tmp[2];
     uint32_t* hist;           // sort scratch: [256 digits][sort blocks] + [256] digit totals
     // Segment checkpoints of the blend (blend_fwd.hip / blend_bwd.hip): the forward leaves every pixel's state in front
-    // of list positions 256, 512, ... of its tile, so that the backward can walk the 256-entry segments of a long list
-    // in parallel.  A tile whose list starts at x and has n > 256 entries owns the slots x / 128 .. x / 128 + (n - 1) / 256
+    // of list positions S, 2 S, ... of its tile (S = GS4D_SEG), so that the backward can walk the S-entry segments of a long
+    // list in parallel.  A tile whose list starts at x and has n > S entries owns the slots x / (S / 2) .. x / (S / 2) + (n - 1) / S
     // (checkpoints 1 .. c, then the final colour / depth record): no two tiles share a slot, nothing is counted.
     float2* ckpt;             // [seg_slots][GS4D_CKPT_FIELDS][128 lanes]: T, C0, C1, C2, depth of the lane's two pixels
     uint2* seg_owner;         // [seg_slots] (tile, segment >= 1) whose backward workgroup this slot is; x = ~0u: none
-    size_t seg_slots;         // R / 128 + 2
+    size_t seg_slots;         // R / GS4D_SEG_SLOT_DIV + 2
     int sorted;               // which ping-pong half holds the sorted lists after `passes` passes
     uint64_t* keys_sorted() const { return keys_tmp[sorted]; }
     uint32_t* point_list() const { return values_tmp[sorted]; }

@@ -75,8 +75,8 @@ int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
  * `debug`: bit 0 as in the reference (synchronise and check after every launch); bit 1
  * (GS4D_FORWARD_ONLY, no reference counterpart) promises that the buffers of this call will not be
  * handed to gs4d_rasterize_backward: the blend then leaves out the per-segment pixel checkpoints
- * (20 bytes per pixel and 256 list entries) from which the backward walks a long tile list in parallel.
- * A backward on buffers of such a call reads undefined checkpoints for tiles with more than 256 entries.
+ * (20 bytes per pixel and 128 list entries) from which the backward walks a long tile list in parallel.
+ * A backward on buffers of such a call reads undefined checkpoints for tiles with more than 128 entries.
  */
 #define GS4D_FORWARD_ONLY 2
 int gs4d_rasterize_forward(
