@@ -307,7 +307,7 @@ def main():
             sec = stage_ms * 1e-3
             tf = pairs_bwd * flop_per_pair / sec / 1e12
             traffic, src = pmc_traffic(kernel)
-            return {"kernel": kernel, "bound": "valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            return {"kernel": kernel.split("<")[0], "bound": "valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
                     "avg_launch_ms": round(stage_ms, 4), "pairs": pairs_bwd, "flop_per_pair": flop_per_pair,
                     "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / sec / 1e9, 2),
@@ -320,14 +320,15 @@ def main():
             # 44 B/instance staged + 40 B/instance gradient rows + 24 B/pixel (dL/dcolor 12, dL/ddepth 4, final_T 4, n_contrib 4)
             roofline = blend_roofline("blend_backward_kernel", stages["blend_backward"], 84.0 * Rn + 24.0 * W * H, 60)
         elif "blend_forward" in stages:
-            roofline = blend_roofline("blend_forward_kernel", stages["blend_forward"], 44.0 * Rn + 24.0 * W * H, 25)
+            roofline = blend_roofline("blend_forward_kernel<false, false>", stages["blend_forward"], 44.0 * Rn + 24.0 * W * H, 25)
 
         render_fps = None
         if fps_dt is not None:
             render_fps = {"metric": "render FPS", "value": round(world * fps_frames / fps_dt, 2), "unit": "frames/s",
                           "ms_per_frame": round(fps_dt / fps_frames * 1e3, 4), "frames": fps_frames, "n_gpus": world,
                           "what": f"render_for_image (deformation forward + rasterizer forward, no grad) of the same scene at {W}x{H}",
-                          "roofline": blend_roofline("blend_forward_kernel", fps_blend_ms, 44.0 * Rn + 24.0 * W * H, 25) if fps_blend_ms else None}
+                          # the forward-only instantiation (no segment checkpoints for a backward)
+                          "roofline": blend_roofline("blend_forward_kernel<false, false>", fps_blend_ms, 44.0 * Rn + 24.0 * W * H, 25) if fps_blend_ms else None}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
