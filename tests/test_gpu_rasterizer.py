@@ -369,3 +369,43 @@ def test_nan_opacity_is_blended_like_the_reference():
     touched = r["tiles_touched"][7]
     assert touched > 0                                     # the NaN splat is on screen, so the case is exercised
     assert np.isfinite(out[1].cpu().numpy()).all()         # 0.99, not NaN, reaches the image (as in the reference)
+
+
+def test_backward_parity_long_lists_many_segments():
+    """Lists of more than a thousand entries on a handful of tiles: the backward walks them in 128-entry segments from the
+    forward's checkpoints (csrc/blend_bwd.hip); low opacities keep most pixels alive to the end of their list, so every
+    segment is live and starts from a checkpoint with a small transmittance."""
+    a, cam = scene(2500, 48, 40, 21, 0.2)
+    a = dict(a, opacities=(a["opacities"] * 0.3).astype(np.float32))
+    r, (R, color, depth, radii, gb, bb, ib) = check_forward(a, cam, 3)
+    v = dgr()._C.state_view(2500, R, 48, 40, gb, bb, ib)
+    lens = (v["ranges"][:, 1] - v["ranges"][:, 0]).cpu().numpy()
+    deepest = int(v["n_contrib"].max().item())
+    print("list lengths", lens.tolist(), "deepest contributor", deepest)
+    assert lens.max() > 1024 and deepest > 640            # at least five live segments on some tile
+    check_backward(a, cam, 3, seed=3)
+
+
+def test_forward_only_flag_changes_no_output():
+    """GS4D_FORWARD_ONLY (debug bit 1, set by the wrapper when no input needs a gradient) only drops the checkpoints."""
+    a, cam = scene(3000, 96, 80, 4, 0.2)
+    C_ = dgr()._C
+    e = torch.Tensor([])
+    args = (torch.ones(3, device="cuda"), dev(a["means3D"]), e, dev(a["opacities"]), dev(a["scales"]), dev(a["rotations"]), 1.0, e,
+            dev(cam.viewmatrix), dev(cam.projmatrix), cam.tanfovx, cam.tanfovy, cam.image_height, cam.image_width, dev(a["sh"]), 3,
+            dev(cam.campos), False, False)
+    R0, c0, d0, r0, g0, b0, i0 = C_.rasterize_gaussians(*args)
+    R1, c1, d1, r1, g1, b1, i1 = C_.rasterize_gaussians_forward_only(*args)
+    assert R0 == R1 and torch.equal(c0, c1) and torch.equal(d0, d1) and torch.equal(r0, r1)
+    v0, v1 = C_.state_view(3000, R0, 96, 80, g0, b0, i0), C_.state_view(3000, R1, 96, 80, g1, b1, i1)
+    for k in ("point_list", "ranges", "n_contrib", "final_T"):
+        assert torch.equal(v0[k], v1[k]), k
+    # the autograd wrapper: identical image with and without gradients
+    rast = dgr().GaussianRasterizer(settings(cam, 3))
+    t = {k: dev(a[k], True) for k in ("means3D", "opacities", "sh", "scales", "rotations")}
+    kw = dict(means3D=t["means3D"], means2D=torch.zeros_like(t["means3D"]), opacities=t["opacities"], shs=t["sh"],
+              scales=t["scales"], rotations=t["rotations"])
+    with torch.no_grad():
+        img_ng, _, _ = rast(**kw)
+    img_g, _, _ = rast(**kw)
+    assert torch.equal(img_ng, img_g) and torch.equal(img_g, c0)
