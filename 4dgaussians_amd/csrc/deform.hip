@@ -277,7 +277,8 @@ __global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
     float4* __restrict__ dcoord,               // [P]: (d/dx, d/dy, d/dz, d/dt') in normalised coordinates
     float* __restrict__ gsix,                  // [P][L][6][C]: dL/d(sample) of every plane
     int* __restrict__ hist,                    // [L][HEX_SORTS][nbins], zeroed by the caller
-    int* __restrict__ rank, int* __restrict__ key)   // [L][HEX_SORTS][P]
+    int* __restrict__ rank, int* __restrict__ key,   // [L][HEX_SORTS][P]
+    int do_rank)                               // 0: the point order is taken from the caller's cache, nothing is ranked
 {
     const int lanes = 1 << lpp_shift;
     const int gtid = blockIdx.x * 256 + threadIdx.x;
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
         pts[3] = tprime[p];
     }
     float dpts[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {                                 // rank the point inside its cell of every level's sort planes
+    if (live && do_rank) {                      // rank the point inside its cell of every level's sort planes
         for (int ls = sub; ls < L * HEX_SORTS; ls += lanes) {    // one (level, sort) per lane of the point
             const int l = ls / HEX_SORTS, s = ls - l * HEX_SORTS;
             const int i = B.plane[s], pl = l * 6 + i;
@@ -397,7 +398,8 @@ __global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int L,
                                                                    const float* __restrict__ tprime,
                                                                    const int* __restrict__ start,
                                                                    const int* __restrict__ rank,
-                                                                   const int* __restrict__ key, float4* __restrict__ rec)
+                                                                   const int* __restrict__ key, float4* __restrict__ rec,
+                                                                   int* __restrict__ order)     // may be null: [L][HEX_SORTS][P], sorted position -> point
 {
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= P) return;
@@ -415,8 +417,30 @@ __global__ __launch_bounds__(256) void hexplane_bin_scatter_kernel(int P, int L,
             const size_t ls = (size_t)l * HEX_SORTS + s;
             const int pos = start[ls * nbins + key[ls * P + p]] + rank[ls * P + p];
             rec[ls * P + pos] = make_float4(__int_as_float(p), ra[s], rb[s], t);
+            if (order) order[ls * P + pos] = p;
         }
     }
+}
+
+// The sorted records from a cached order (gs4d_deform_grads::hex_order): position -> point as recorded by an earlier
+// backward, coordinates as they are now.
+__global__ __launch_bounds__(256) void hexplane_rec_from_order_kernel(int P, int L, const float* __restrict__ aabb,
+                                                                      const float* __restrict__ xyz,
+                                                                      const float* __restrict__ tprime,
+                                                                      const int* __restrict__ order, float4* __restrict__ rec)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)L * HEX_SORTS * P) return;
+    const int s = (int)((e / P) % HEX_SORTS);
+    const int p = min(max(order[e], 0), P - 1);
+    float pts[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lo = aabb[a], hi = aabb[3 + a];
+        pts[a] = (xyz[3 * (size_t)p + a] - lo) * (2.0f / (hi - lo)) - 1.0f;
+    }
+    const float ra = s == 1 ? pts[1] : pts[0], rb = s == 0 ? pts[1] : pts[2];
+    rec[e] = make_float4(__int_as_float(p), ra, rb, tprime[p]);
 }
 
 // blockIdx.y = level * 6 + plane.  A group of min(C, 64) lanes (one per channel) walks HEX_RPW * HEX_RUN
@@ -2123,6 +2147,9 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         }
         // batches of HB points (one batch unless the scene is large, see hex_batch_points): the sorted records and
         // gsix carry batch-local point indices, the plane gradients accumulate over the batches
+        const bool one_batch = HB >= (size_t)P;
+        const bool reuse_order = one_batch && g->hex_order && g->hex_order_valid;
+        int* record_order = (one_batch && g->hex_order && !g->hex_order_valid) ? g->hex_order : nullptr;
         for (size_t p0 = 0; p0 < (size_t)P; p0 += HB) {
             const int n = (int)(((size_t)P - p0) < HB ? ((size_t)P - p0) : HB);
             if (p0 > 0) GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, s));     // the first batch's zeros come from pe_backward
@@ -2131,10 +2158,16 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
             const size_t threads = (size_t)n << lpp_shift;
             hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n,
                                d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * l.F, l.F,
-                               (float4*)dxyz_hex + p0, gsix, hist, rank, key);
-            hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS * d->L), dim3(1024), 0, s, B.nbins, hist);
-            hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d->L, B.nbins, d->aabb,
-                               pts_b, tp_b, hist, rank, key, rec);
+                               (float4*)dxyz_hex + p0, gsix, hist, rank, key, reuse_order ? 0 : 1);
+            if (reuse_order) {
+                const size_t ne = (size_t)d->L * HEX_SORTS * n;
+                hipLaunchKernelGGL(hexplane_rec_from_order_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, n, d->L,
+                                   d->aabb, pts_b, tp_b, g->hex_order, rec);
+            } else {
+                hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS * d->L), dim3(1024), 0, s, B.nbins, hist);
+                hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d->L, B.nbins, d->aabb,
+                                   pts_b, tp_b, hist, rank, key, rec, record_order);
+            }
             hipLaunchKernelGGL(kern, dim3((unsigned)(((size_t)n + per_wg - 1) / per_wg), 6 * d->L), dim3(256), lds, s, n, d->C,
                                d->L, T, rec, gsix);
         }

@@ -39,7 +39,38 @@ class DeformDesc(C.Structure):
 class DeformGrads(C.Structure):
     _fields_ = [("planes", FP * (MAX_LEVELS * 6)), ("ft_w", FP), ("ft_b", FP), ("trunk_w", FP * MAX_TRUNK),
                 ("trunk_b", FP * MAX_TRUNK), ("head_w1", FP * 4), ("head_b1", FP * 4), ("head_w2", FP * 4),
-                ("head_b2", FP * 4)]
+                ("head_b2", FP * 4), ("hex_order", C.c_void_p), ("hex_order_valid", C.c_int), ("reserved_", C.c_int)]
+
+
+class HexOrderCache:
+    """The plane-gradient pipeline's point order, kept from one backward to the next (gs4d_deform_grads::hex_order,
+    include/gs4d.h): the order only decides which gradient adds are combined before they reach memory, never the result,
+    and the points move little per iteration, so the ranking atomics, the bin scan and the scatter run only every
+    `refresh` backward passes (GS4D_HEX_ORDER_REFRESH, default 16; 0 switches the cache off) and whenever the number of
+    points, the device or the level count changes.  One entry per point count (the regularised render queries 3 P points)."""
+
+    def __init__(self):
+        import os
+        self.refresh = int(os.environ.get("GS4D_HEX_ORDER_REFRESH", "16"))
+        self.entries = {}
+
+    def clear(self):
+        self.entries.clear()
+
+    def bind(self, g, P, L, dev):
+        """Points `g` at the order buffer for (P, L, dev) and says whether it holds a usable order."""
+        if self.refresh <= 0 or P == 0:
+            g.hex_order, g.hex_order_valid = None, 0
+            return
+        key = (P, L, dev.index)
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= 4:
+                self.entries.clear()
+            e = self.entries[key] = [torch.empty(L * 3 * P, dtype=torch.int32, device=dev), self.refresh]
+        valid = e[1] < self.refresh
+        e[1] = e[1] + 1 if valid else 1
+        g.hex_order, g.hex_order_valid = e[0].data_ptr(), int(valid)
 
 
 def _lib():
@@ -232,6 +263,11 @@ class _DeformFunction(torch.autograd.Function):
         scratch = torch.empty(max(int(L.gs4d_deform_backward_scratch_bytes(C.byref(d), C.c_int(P))), 256),
                               dtype=torch.uint8, device=dev)
         hook = cfg.get("data_grad_hook")
+        order_cache = cfg.get("hex_order_cache")
+        if order_cache is not None:
+            order_cache.bind(g, P, int(d.L), dev)
+        else:
+            g.hex_order, g.hex_order_valid = None, 0
 
         def run(phases):
             with torch.cuda.device(dev):
@@ -281,6 +317,7 @@ class Deformation(nn.Module):
     def set_aabb(self, xyz_max, xyz_min):
         self.grid.set_aabb(xyz_max, xyz_min)      # replaces grid.aabb by a new Parameter: the cached plan is stale
         self._step_cache = None
+        self.__dict__.pop("_hex_order_cache", None)   # other bounds, other cells: the cached point order is void
 
     def create_net(self):
         W = self.W
@@ -351,10 +388,12 @@ class Deformation(nn.Module):
     def __getstate__(self):                        # the step cache holds ctypes structures: never pickled / deep-copied
         state = dict(super().__getstate__()) if hasattr(super(), "__getstate__") else dict(self.__dict__)
         state.pop("_step_cache", None)
+        state.pop("_hex_order_cache", None)
         return state
 
     def _apply(self, fn, *a, **k):                 # .to() / .cuda() / .float(): parameters may get new storage
         self._step_cache = None
+        self.__dict__.pop("_hex_order_cache", None)
         return super()._apply(fn, *a, **k)
 
     def forward_dynamic(self, points, scales, rotations, opacity, shs, time, force, prev_frames=None):
@@ -372,6 +411,10 @@ class Deformation(nn.Module):
             cache = self.__dict__["_step_cache"] = (params, cfg, self._flags(), self.grid.aabb)
         params, cfg = cache[0], cache[1]
         cfg["data_grad_hook"] = self.data_grad_hook
+        oc = self.__dict__.get("_hex_order_cache")
+        if oc is None:
+            oc = self.__dict__["_hex_order_cache"] = HexOrderCache()
+        cfg["hex_order_cache"] = oc
         out = _DeformFunction.apply(points, scales, rotations, shs, time, force, cfg, *params)
         # opacity passes through (no_do): the reference's opacity[:, :1] is the tensor itself when it is (P, 1)
         return out[0], out[1], out[2], opacity if opacity.shape[1] == 1 else opacity[:, :1], out[3]

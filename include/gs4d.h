@@ -267,6 +267,16 @@ typedef struct gs4d_deform_grads {
     float* head_b1[4];
     float* head_w2[4];
     float* head_b2[4];
+    /* Optional cache of the plane-gradient pipeline's point order (no reference counterpart; NULL: off).  The backward
+     * sorts the points by plane cell only to COMBINE gradient adds before they reach memory -- its results do not depend
+     * on that order -- and the points of a scene move little from one iteration to the next.  hex_order: device
+     * [L * 3 * P] ints owned by the caller.  hex_order_valid = 0: the backward sorts as usual and leaves the order here;
+     * 1: it skips the ranking atomics, the bin scan and the scatter and walks the points in the cached order (same P
+     * and L as when it was recorded; a stale order only groups a little less well).  Ignored when the scene is large
+     * enough for the pipeline to run in several batches. */
+    int* hex_order;
+    int hex_order_valid;
+    int reserved_;
 } gs4d_deform_grads;
 
 /* Bytes of the activation workspace the forward fills and the backward re-reads, and of the

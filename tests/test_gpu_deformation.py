@@ -171,3 +171,59 @@ def test_set_aabb_and_extra_deform_switches_take_effect_after_a_forward():
     fourth = both(cfg)
     for a, b in zip(second, fourth):
         assert torch.equal(a, b)
+
+
+def test_cached_point_order_changes_no_gradient():
+    """The plane-gradient pipeline may walk the points in the order an EARLIER backward recorded (HexOrderCache,
+    gs4d_deform_grads::hex_order): the order only decides which adds are combined before they reach memory.  Same inputs:
+    the gradients of the recording pass and of a reusing pass agree to the rounding of the float atomics; after every
+    point has moved somewhere else (the cached order is then as bad as a random one) they still agree with a fresh sort."""
+    from oracle import deformation_ref as R
+    cfg = R.DeformConfig(defor_depth=1, plane_channels=16, resolution=[32, 32, 32, 8], multires=[1, 2])
+    torch.manual_seed(5)
+    net = pkg("scene.deformation").deform_network(make_args(cfg))
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if "deform" in n and "bias" in n:
+                p.add_(0.05 * torch.randn_like(p))
+    net = net.cuda()
+    dn = net.deformation_net
+    P = 20000
+    g = torch.Generator().manual_seed(3)
+    base = [torch.rand(P, 3, generator=g) * 2 - 1, torch.randn(P, 3, generator=g) * 0.5 - 3, torch.randn(P, 4, generator=g),
+            torch.randn(P, 1, generator=g), torch.randn(P, 16, 3, generator=g) * 0.3]
+    time, force = torch.full((P, 1), 0.37).cuda(), torch.zeros(P, 1).cuda()
+    w = [torch.randn_like(t).cuda() for t in base]
+    planes = [p for level in dn.grid.grids for p in level]
+
+    def grads(points):
+        x = [points.cuda().requires_grad_(True)] + [t.cuda().requires_grad_(True) for t in base[1:]]
+        for p in net.parameters():
+            p.grad = None
+        out = net.forward_dynamic(*x, time, force, None)
+        sum((o * wi).sum() for o, wi in zip(out, w)).backward()
+        return [p.grad.clone() for p in planes] + [x[0].grad.clone()]
+
+    def same(a, b, tol):
+        for u, v in zip(a, b):
+            assert float((u - v).abs().max()) <= tol * max(float(v.abs().max()), 1e-20)
+
+    recorded = grads(base[0])                                  # sorts, leaves the order in the cache
+    cache = dn.__dict__["_hex_order_cache"]
+    entry = cache.entries[(P, 2, 0)]
+    assert entry[1] == 1
+    reused = grads(base[0])                                    # walks the cached order
+    assert entry[1] == 2
+    same(reused, recorded, 2e-6)
+    moved = base[0][torch.randperm(P, generator=g)]            # every point somewhere else: the cached order is stale
+    stale = grads(moved)
+    assert entry[1] == 3
+    cache.clear()
+    fresh = grads(moved)
+    assert cache.entries[(P, 2, 0)][1] == 1
+    same(stale, fresh, 2e-6)
+    entry = cache.entries[(P, 2, 0)]
+    entry[1] = cache.refresh                                   # due for a refresh: the next backward sorts again
+    again = grads(moved)
+    assert entry[1] == 1
+    same(again, fresh, 2e-6)
