@@ -175,11 +175,13 @@ __global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_hist_kernel(uint32_t R
     s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t base = blockIdx.x * GS4D_SORT_TILE;
+    uint32_t d[GS4D_SORT_ITEMS];
 #pragma unroll
-    for (int i = 0; i < GS4D_SORT_ITEMS; i++) {
-        const uint32_t k = base + i * GS4D_SORT_THREADS + threadIdx.x;
-        if (k < R) atomicAdd(&s_h[(uint32_t)(keys[k] >> shift) & 255u], 1u);
-    }
+    for (int i = 0; i < GS4D_SORT_ITEMS; i++)          // unconditional, clamped: all loads in flight together
+        d[i] = (uint32_t)(keys[min(base + i * GS4D_SORT_THREADS + threadIdx.x, R - 1u)] >> shift) & 255u;
+#pragma unroll
+    for (int i = 0; i < GS4D_SORT_ITEMS; i++)
+        if (base + i * GS4D_SORT_THREADS + threadIdx.x < R) atomicAdd(&s_h[d[i]], 1u);
     __syncthreads();
     hist[(size_t)threadIdx.x * ntiles + blockIdx.x] = s_h[threadIdx.x];
 }
@@ -235,26 +237,43 @@ __global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_scatter_kernel(
     const uint32_t wave_base = tile_base + wave * (64 * GS4D_SORT_ITEMS);
     uint64_t key[GS4D_SORT_ITEMS];
     uint32_t val[GS4D_SORT_ITEMS];
-    uint32_t rank[GS4D_SORT_ITEMS];   // rank among equal digits inside this wave's 512 keys
+    uint32_t rank[GS4D_SORT_ITEMS];   // rank among equal digits inside this wave's keys
     const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+    // loads unconditional with clamped addresses (a load under a branch is waited for before the next one is issued:
+    // the eight key / value pairs of a lane then cost eight memory latencies in a row)
 #pragma unroll
     for (int r = 0; r < GS4D_SORT_ITEMS; r++) {
-        const uint32_t k = wave_base + r * 64 + lane;
-        const bool valid = k < R;
-        key[r] = valid ? keys_in[k] : ~0ull;
-        val[r] = valid ? vals_in[k] : 0u;
-        const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-        const uint64_t same = match_digit(d, valid);   // lanes holding the same digit
-        const uint32_t before = (uint32_t)__popcll(same & lanemask_lt);
-        const int leader = __ffsll((unsigned long long)same) - 1;
-        uint32_t prev = 0;
-        if (valid && lane == leader) {
-            prev = s_cnt[wave][d];
-            s_cnt[wave][d] = prev + (uint32_t)__popcll(same);
-        }
-        prev = __shfl(prev, leader, 64);
-        rank[r] = prev + before;
+        const uint32_t k = min(wave_base + r * 64 + lane, R - 1u);
+        key[r] = keys_in[k];
+        val[r] = vals_in[k];
     }
+    // ranking as in the per-tile sort: the register-only part of every round first, then ONE chain through the LDS
+    // counters, then the shuffles
+    uint32_t before[GS4D_SORT_ITEMS], group[GS4D_SORT_ITEMS];
+    int leader[GS4D_SORT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < GS4D_SORT_ITEMS; r++) {
+        const bool valid = wave_base + r * 64 + lane < R;
+        if (!valid) key[r] = ~0ull;
+        const uint64_t same = match_digit((uint32_t)(key[r] >> shift) & 255u, valid);   // lanes holding the same digit
+        before[r] = (uint32_t)__popcll(same & lanemask_lt);
+        leader[r] = __ffsll((unsigned long long)same) - 1;
+        group[r] = (uint32_t)__popcll(same);
+    }
+#pragma unroll
+    for (int r = 0; r < GS4D_SORT_ITEMS; r++) {
+        rank[r] = 0u;
+        if (wave_base + r * 64 + lane < R && lane == leader[r]) {
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            rank[r] = s_cnt[wave][d];
+            s_cnt[wave][d] = rank[r] + group[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the next round's leaders read what this one's wrote
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int r = 0; r < GS4D_SORT_ITEMS; r++) rank[r] = (uint32_t)__shfl((int)rank[r], leader[r], 64) + before[r];
     __syncthreads();
 
     // per digit: exclusive offsets across the 4 waves, tile total, and exclusive scan over digits
