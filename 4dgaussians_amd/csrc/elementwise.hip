@@ -85,9 +85,27 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(size_t n, const float* 
                                                          float* __restrict__ partial)
 {
     __shared__ float s[256];
-    float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)L1_BLOCKS * 256) acc += fabsf(a[i] - b[i]);
-    const float t = block_sum_256(acc, s);
+    // float4 rows, two per trip, four independent partial sums per lane (fixed order: deterministic); the callers' tensors
+    // are 16-byte aligned (checked by the entry point), the last n % 4 elements go to one lane
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    const size_t n4 = n >> 2, stride = (size_t)L1_BLOCKS * 256;
+    const float4* __restrict__ a4 = reinterpret_cast<const float4*>(a);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b);
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < n4; i += 2 * stride) {
+        const float4 x0 = a4[i], y0 = b4[i], x1 = a4[i + stride], y1 = b4[i + stride];
+        acc0 += fabsf(x0.x - y0.x) + fabsf(x1.x - y1.x);
+        acc1 += fabsf(x0.y - y0.y) + fabsf(x1.y - y1.y);
+        acc2 += fabsf(x0.z - y0.z) + fabsf(x1.z - y1.z);
+        acc3 += fabsf(x0.w - y0.w) + fabsf(x1.w - y1.w);
+    }
+    if (i < n4) {
+        const float4 x0 = a4[i], y0 = b4[i];
+        acc0 += fabsf(x0.x - y0.x); acc1 += fabsf(x0.y - y0.y); acc2 += fabsf(x0.z - y0.z); acc3 += fabsf(x0.w - y0.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t t = n4 << 2; t < n; t++) acc0 += fabsf(a[t] - b[t]);
+    const float t = block_sum_256((acc0 + acc1) + (acc2 + acc3), s);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
@@ -105,10 +123,17 @@ __global__ __launch_bounds__(256) void l1_backward_kernel(size_t n, const float*
                                                           const float* __restrict__ g_loss, float* __restrict__ d_a)
 {
     const float k = g_loss[0] / (float)n;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float d = a[i] - b[i];
-        d_a[i] = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+    auto sgn = [k](float d) { return d > 0.f ? k : (d < 0.f ? -k : 0.f); };
+    const size_t n4 = n >> 2;
+    const float4* __restrict__ a4 = reinterpret_cast<const float4*>(a);
+    const float4* __restrict__ b4 = reinterpret_cast<const float4*>(b);
+    float4* __restrict__ d4 = reinterpret_cast<float4*>(d_a);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 x = a4[i], y = b4[i];
+        d4[i] = make_float4(sgn(x.x - y.x), sgn(x.y - y.y), sgn(x.z - y.z), sgn(x.w - y.w));
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t t = n4 << 2; t < n; t++) d_a[t] = sgn(a[t] - b[t]);
 }
 
 }  // namespace
@@ -159,6 +184,10 @@ int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratc
         gs4d_set_error("gs4d_l1_loss_forward: empty input or null pointer");
         return GS4D_EINVAL;
     }
+    if (((uintptr_t)a | (uintptr_t)b) & 15) {
+        gs4d_set_error("gs4d_l1_loss_forward: a and b must be 16-byte aligned");
+        return GS4D_EINVAL;
+    }
     hipStream_t s = (hipStream_t)stream;
     GS4D_PROF("l1_loss_forward", s);
     hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), dim3(256), 0, s, n, a, b, scratch);
@@ -171,6 +200,10 @@ int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float*
 {
     if (n == 0 || !a || !b || !g_loss || !d_a) {
         gs4d_set_error("gs4d_l1_loss_backward: empty input or null pointer");
+        return GS4D_EINVAL;
+    }
+    if (((uintptr_t)a | (uintptr_t)b | (uintptr_t)d_a) & 15) {
+        gs4d_set_error("gs4d_l1_loss_backward: a, b and d_a must be 16-byte aligned");
         return GS4D_EINVAL;
     }
     hipStream_t s = (hipStream_t)stream;

@@ -335,7 +335,8 @@ int gs4d_activate_backward(int P, const float* scales, const float* rotations, c
                            float* d_log_scales, float* d_rotations, float* d_opacity_logit, void* stream);
 
 /* loss[0] = mean |a[i] - b[i]| over n floats (deterministic two-pass reduction; scratch of
- * gs4d_l1_loss_scratch_bytes()); backward writes d_a[i] = sign(a[i]-b[i]) * g_loss[0] / n. */
+ * gs4d_l1_loss_scratch_bytes()); backward writes d_a[i] = sign(a[i]-b[i]) * g_loss[0] / n.
+ * a, b and d_a must be 16-byte aligned (float4 accesses). */
 size_t gs4d_l1_loss_scratch_bytes(void);
 int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream);
 int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float* g_loss, float* d_a, void* stream);
