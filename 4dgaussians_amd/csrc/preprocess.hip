@@ -16,7 +16,7 @@ using namespace gs4d;
 
 namespace {
 
-__device__ __forceinline__ float3 sh_to_rgb(int deg, const float* __restrict__ sh, const float3 dir, bool* neg)
+__device__ __forceinline__ float3 sh_to_rgb(int deg, const float* sh, const float3 dir, bool* neg)
 {
     float out[3];
     const float x = dir.x, y = dir.y, z = dir.z;
@@ -70,8 +70,30 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     uint32_t my_tiles = 0;
     int my_radius_i = 0;
     int bad = 0;
+    // Every input of the Gaussian is requested up front, before the first test that could skip it: under the near-plane /
+    // empty-rectangle branches the scales, the rotation, the opacity and the 48 SH floats were three memory latencies in
+    // a row (17.5 us at 100 k Gaussians, where the data needs 5).  The arithmetic is unchanged.
+    const int ld = min(idx, P - 1);
+    const float3 p_in = make_float3(means3D[3 * ld], means3D[3 * ld + 1], means3D[3 * ld + 2]);
+    float3 sc_in = make_float3(0.f, 0.f, 0.f);
+    float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cov3D_precomp == nullptr) {                     // uniform
+        sc_in = make_float3(scales[3 * ld], scales[3 * ld + 1], scales[3 * ld + 2]);
+        q_in = reinterpret_cast<const float4*>(rotations)[ld];
+    }
+    const float op_in = opacities[ld];
+    float sh_in[48];
+    const bool sh_regs = colors_precomp == nullptr && M == 16 && (((uintptr_t)shs) & 15) == 0;   // uniform
+    if (sh_regs) {
+        const float4* __restrict__ s4 = reinterpret_cast<const float4*>(shs + (size_t)ld * 48);
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const float4 t = s4[k];
+            sh_in[4 * k] = t.x; sh_in[4 * k + 1] = t.y; sh_in[4 * k + 2] = t.z; sh_in[4 * k + 3] = t.w;
+        }
+    }
     if (idx < P) {
-        const float3 p_orig = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        const float3 p_orig = p_in;
         const float3 p_view = affine_point(p_orig, s_view);
         if (p_view.z > 0.2f) {
             const float4 p_hom = projective_point(p_orig, s_proj);
@@ -83,9 +105,8 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
 #pragma unroll
                 for (int k = 0; k < 6; k++) c3[k] = cov3D_precomp[6 * (size_t)idx + k];
             } else {
-                const float3 sc = make_float3(scale_modifier * scales[3 * idx], scale_modifier * scales[3 * idx + 1],
-                                              scale_modifier * scales[3 * idx + 2]);
-                const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+                const float3 sc = make_float3(scale_modifier * sc_in.x, scale_modifier * sc_in.y, scale_modifier * sc_in.z);
+                const float4 q = q_in;
                 const Mat3 Mm = mat3_product(scale_columns(sc), quat_columns(q));
                 const Mat3 Sigma = mat3_product(mat3_transposed(Mm), Mm);
                 c3[0] = Sigma.e[0][0]; c3[1] = Sigma.e[0][1]; c3[2] = Sigma.e[0][2];
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
                         const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
                         dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
                         bool neg[3];
-                        const float3 col = sh_to_rgb(D, shs + (size_t)idx * M * 3, dir, neg);
+                        const float3 col = sh_regs ? sh_to_rgb(D, sh_in, dir, neg) : sh_to_rgb(D, shs + (size_t)idx * M * 3, dir, neg);
                         rgb[3 * (size_t)idx + 0] = col.x;
                         rgb[3 * (size_t)idx + 1] = col.y;
                         rgb[3 * (size_t)idx + 2] = col.z;
@@ -124,7 +145,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
                     }
                     depths[idx] = p_view.z;
                     means2D[idx] = make_float2(pix_x, pix_y);
-                    conic_opacity[idx] = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, opacities[idx]);
+                    conic_opacity[idx] = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, op_in);
                     my_radius_i = (int)my_radius;
                     my_tiles = ntiles;
                 }
