@@ -112,14 +112,20 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * GS4D_PRE_BLOCK + tid;
     uint32_t cnt = 0;
-    if (idx < P) {
-        cnt = tiles_touched[idx];
-        if (cnt) {
-            const float2 m = means2D[idx];
-            int x0, y0, x1, y1;
-            tile_rect(m.x, m.y, radii[idx], gx, gy, x0, y0, x1, y1);
-            s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
-            s_depth[tid] = __float_as_uint(depths[idx]);
+    {   // the four inputs requested together (clamped index), not one latency after the other under the tests
+        const int ld = min(idx, P - 1);
+        const uint32_t c_in = tiles_touched[ld];
+        const float2 m = means2D[ld];
+        const int r_in = radii[ld];
+        const float d_in = depths[ld];
+        if (idx < P) {
+            cnt = c_in;
+            if (cnt) {
+                int x0, y0, x1, y1;
+                tile_rect(m.x, m.y, r_in, gx, gy, x0, y0, x1, y1);
+                s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
+                s_depth[tid] = __float_as_uint(d_in);
+            }
         }
     }
     uint32_t incl = cnt;

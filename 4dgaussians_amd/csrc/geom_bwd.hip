@@ -280,18 +280,20 @@ __global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= A.P) return;
-    if (!(A.radii[idx] > 0)) {
+    // requested together (under the tests below they were three memory latencies in a row)
+    const int radius = A.radii[idx];
+    const uint32_t cnt = A.tiles_touched[idx];
+    const uint32_t end = A.point_offsets[idx];
+    if (!(radius > 0)) {
         // dL_dmean2D is written in full (the caller may hand over uninitialised memory for it, see include/gs4d.h)
         A.dL_dmean2D[3 * idx + 0] = 0.f; A.dL_dmean2D[3 * idx + 1] = 0.f; A.dL_dmean2D[3 * idx + 2] = 0.f;
         return;
     }
-    const uint32_t cnt = A.tiles_touched[idx];
     if (cnt > GS4D_BIG_ROWS) {
         const uint32_t slot = atomicAdd(A.big_count, 1u);
         A.big_list[slot] = (uint32_t)idx;
         return;
     }
-    const uint32_t end = A.point_offsets[idx];
     const uint32_t first = end - cnt;
     // The rows are summed in DOUBLE: the kernel waits on memory ~90 % of the time, so the wider adds are free, and the
     // sums then carry only the rounding of the per-tile partials (the reference's float atomics add in arbitrary order;
