@@ -667,3 +667,280 @@ extern "C" int gs4d_temporal_regulation_backward(int n, int k, int sh_floats, co
     GS4D_LAUNCH_CHECK("temporal_regulation_backward", 0, s);
     return GS4D_OK;
 }
+
+// ------------------------------------------------------------------ transposed neighbour graph (order, row_start)
+// The pairs p = i*k+s sorted by their target idx[p], stable (ascending p inside a target), and where each target's run
+// begins: what every gather backward above reads.  A least-significant-digit radix sort over exactly the bits the targets
+// have -- ceil(log2 n) of them in digits of up to nine bits: two passes up to n = 262 144 -- with 32-bit keys, the pair
+// index made up in the first pass instead of read, and row_start taken from the sorted keys by a bounds kernel.
+// (The host-side version was a 32-bit torch.sort: four passes with 64-bit indices, an index fill before it, a searchsorted
+// and two dtype conversions after it.)  Pass structure as in csrc/binning.hip: per-tile digit histogram, one scan per
+// digit over the tiles, then a stable scatter that ranks with wave ballots and per-wave LDS counters.
+namespace {
+
+#define TG_THREADS 256
+#define TG_ITEMS 8
+#define TG_TILE (TG_THREADS * TG_ITEMS)
+#define TG_BINS 512
+
+// lanes of the wave whose digit (<= 9 bits; a narrower digit's upper bits are zero and change nothing) equals this lane's;
+// invalid lanes form their own group
+__device__ __forceinline__ uint64_t tg_match(uint32_t d, bool valid)
+{
+    const uint64_t vm = __ballot(valid);
+    uint32_t lo = (uint32_t)vm, hi = (uint32_t)(vm >> 32);
+    if (!valid) { lo = ~lo; hi = ~hi; }
+#pragma unroll
+    for (int b = 0; b < 9; b++) {
+        const uint32_t bit = (d >> b) & 1u;
+        const uint64_t mb = __builtin_amdgcn_uicmp(bit, 0u, 33);    // v_cmp_ne_u32 = the ballot
+        const uint32_t neg = 0u - bit;
+        lo &= ~((uint32_t)mb ^ neg);
+        hi &= ~((uint32_t)(mb >> 32) ^ neg);
+    }
+    return ((uint64_t)hi << 32) | (uint64_t)lo;
+}
+
+// hist[digit][tile]
+__global__ __launch_bounds__(TG_THREADS) void tg_hist_kernel(uint32_t R, int shift, int bits, const uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ hist, uint32_t ntiles)
+{
+    __shared__ uint32_t s_h[TG_BINS];
+    const uint32_t mask = (1u << bits) - 1u;
+    s_h[threadIdx.x] = 0; s_h[threadIdx.x + 256] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * TG_TILE;
+    uint32_t d[TG_ITEMS];
+#pragma unroll
+    for (int i = 0; i < TG_ITEMS; i++) d[i] = (keys[min(base + i * TG_THREADS + threadIdx.x, R - 1u)] >> shift) & mask;
+#pragma unroll
+    for (int i = 0; i < TG_ITEMS; i++)
+        if (base + i * TG_THREADS + threadIdx.x < R) atomicAdd(&s_h[d[i]], 1u);
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b <= mask; b += TG_THREADS) hist[(size_t)b * ntiles + blockIdx.x] = s_h[b];
+}
+
+// workgroup d: exclusive scan of row d of hist in place, row total -> digit_totals[d]
+__global__ __launch_bounds__(256) void tg_scan_kernel(uint32_t ntiles, uint32_t* __restrict__ hist, uint32_t* __restrict__ digit_totals)
+{
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_carry;
+    uint32_t* row = hist + (size_t)blockIdx.x * ntiles;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t b = 0; b < ntiles; b += 1024) {
+        // four consecutive tiles per lane: a quarter of the barriers
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t i = b + 4 * threadIdx.x + q; v[q] = i < ntiles ? row[i] : 0u; sum += v[q]; }
+        uint32_t incl = sum;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wp = 0;
+        for (int w = 0; w < wave; w++) wp += s_wave[w];
+        const uint32_t carry = s_carry;
+        uint32_t run = carry + wp + incl - sum;
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const uint32_t i = b + 4 * threadIdx.x + q; if (i < ntiles) row[i] = run; run += v[q]; }
+        __syncthreads();
+        if (threadIdx.x == 255) s_carry = run;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) digit_totals[blockIdx.x] = s_carry;
+}
+
+// FIRST: the values are the positions themselves (nothing to read)
+template <bool FIRST>
+__global__ __launch_bounds__(TG_THREADS) void tg_scatter_kernel(uint32_t R, int shift, int bits, const uint32_t* __restrict__ keys_in,
+                                                                const uint32_t* __restrict__ vals_in, uint32_t* __restrict__ keys_out,
+                                                                uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ hist,
+                                                                const uint32_t* __restrict__ digit_totals, uint32_t ntiles)
+{
+    __shared__ uint32_t s_cnt[4][TG_BINS];        // per-wave digit counts -> exclusive offsets inside the tile
+    __shared__ uint32_t s_digit_start[TG_BINS];   // first staged slot of each digit inside the tile
+    __shared__ uint32_t s_global[TG_BINS];        // global output position of that first slot
+    __shared__ uint32_t s_wave[4];
+    __shared__ uint32_t s_keys[TG_TILE];
+    __shared__ uint32_t s_vals[TG_TILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t mask = (1u << bits) - 1u;
+    for (int i = tid; i < 4 * TG_BINS; i += TG_THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+
+    const uint32_t tile_base = blockIdx.x * TG_TILE;
+    const uint32_t wave_base = tile_base + wave * (64 * TG_ITEMS);     // (wave, round, lane) order == memory order: stable
+    uint32_t key[TG_ITEMS], val[TG_ITEMS], rank[TG_ITEMS];
+    const uint64_t lanemask_lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int r = 0; r < TG_ITEMS; r++) {                               // unconditional, clamped: all loads in flight together
+        const uint32_t p = min(wave_base + r * 64 + lane, R - 1u);
+        key[r] = keys_in[p];
+        val[r] = FIRST ? p : vals_in[p];
+    }
+    uint32_t before[TG_ITEMS], group[TG_ITEMS];
+    int leader[TG_ITEMS];
+#pragma unroll
+    for (int r = 0; r < TG_ITEMS; r++) {
+        const bool valid = wave_base + r * 64 + lane < R;
+        const uint64_t same = tg_match((key[r] >> shift) & mask, valid);
+        before[r] = (uint32_t)__popcll(same & lanemask_lt);
+        leader[r] = __ffsll((unsigned long long)same) - 1;
+        group[r] = (uint32_t)__popcll(same);
+    }
+#pragma unroll
+    for (int r = 0; r < TG_ITEMS; r++) {
+        rank[r] = 0u;
+        if (wave_base + r * 64 + lane < R && lane == leader[r]) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            rank[r] = s_cnt[wave][d];
+            s_cnt[wave][d] = rank[r] + group[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          // the next round's leaders read what this one's wrote
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int r = 0; r < TG_ITEMS; r++) rank[r] = (uint32_t)__shfl((int)rank[r], leader[r], 64) + before[r];
+    __syncthreads();
+
+    // lane tid owns digits 2 tid and 2 tid + 1: offsets across the four waves, then exclusive scans over the digits
+    {
+        uint32_t tot[2], dt[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int d = 2 * tid + q;
+            const uint32_t c0 = s_cnt[0][d], c1 = s_cnt[1][d], c2 = s_cnt[2][d], c3 = s_cnt[3][d];
+            s_cnt[0][d] = 0; s_cnt[1][d] = c0; s_cnt[2][d] = c0 + c1; s_cnt[3][d] = c0 + c1 + c2;
+            tot[q] = c0 + c1 + c2 + c3;
+            dt[q] = (uint32_t)d <= mask ? digit_totals[d] : 0u;
+        }
+        const uint32_t pair = tot[0] + tot[1], dpair = dt[0] + dt[1];
+        uint32_t incl = pair, dincl = dpair;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64), u = __shfl_up(dincl, off, 64);
+            if (lane >= off) { incl += t; dincl += u; }
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wp = 0;
+        for (int w = 0; w < wave; w++) wp += s_wave[w];
+        __syncthreads();
+        if (lane == 63) s_wave[wave] = dincl;
+        __syncthreads();
+        uint32_t smaller = 0;
+        for (int w = 0; w < wave; w++) smaller += s_wave[w];
+        const uint32_t start0 = wp + incl - pair, small0 = smaller + dincl - dpair;
+        s_digit_start[2 * tid] = start0;
+        s_digit_start[2 * tid + 1] = start0 + tot[0];
+        // global position = (keys with a smaller digit anywhere) + (same digit in earlier tiles)
+        s_global[2 * tid] = small0 + ((uint32_t)(2 * tid) <= mask ? hist[(size_t)(2 * tid) * ntiles + blockIdx.x] : 0u);
+        s_global[2 * tid + 1] = small0 + dt[0] + ((uint32_t)(2 * tid + 1) <= mask ? hist[(size_t)(2 * tid + 1) * ntiles + blockIdx.x] : 0u);
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int r = 0; r < TG_ITEMS; r++) {
+        if (wave_base + r * 64 + lane < R) {
+            const uint32_t d = (key[r] >> shift) & mask;
+            const uint32_t slot = s_digit_start[d] + s_cnt[wave][d] + rank[r];
+            s_keys[slot] = key[r];
+            s_vals[slot] = val[r];
+        }
+    }
+    __syncthreads();
+
+    const uint32_t n_valid = min((uint32_t)TG_TILE, R - tile_base);
+    for (uint32_t i = tid; i < n_valid; i += TG_THREADS) {
+        const uint32_t kk = s_keys[i];
+        const uint32_t d = (kk >> shift) & mask;
+        const uint32_t dst = s_global[d] + (i - s_digit_start[d]);
+        keys_out[dst] = kk;
+        vals_out[dst] = s_vals[i];
+    }
+}
+
+// row_start[t] = first position whose key is >= t, for t = 0..n (row_start[n] = R); keys are sorted
+__global__ __launch_bounds__(256) void tg_bounds_kernel(uint32_t R, int n, const uint32_t* __restrict__ keys, int* __restrict__ row_start)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i > R) return;
+    const int a = i == 0 ? -1 : (int)min(keys[i - 1], (uint32_t)n);
+    const int b = i == R ? n : (int)min(keys[i], (uint32_t)n);
+    for (int t = a + 1; t <= b; t++) row_start[t] = (int)i;
+}
+
+struct TgPlan { int passes, width; size_t R, ntiles, off_k[2], off_v[2], off_hist, off_tot, bytes; };
+
+TgPlan tg_plan(int n, size_t R)
+{
+    TgPlan p;
+    int bits = 1;
+    while (bits < 31 && ((size_t)1 << bits) < (size_t)n) bits++;
+    p.passes = (bits + 8) / 9;
+    p.width = (bits + p.passes - 1) / p.passes;
+    p.R = R;
+    p.ntiles = (R + TG_TILE - 1) / TG_TILE;
+    auto up = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    size_t o = 0;
+    p.off_k[0] = o; o += up(4 * R);
+    p.off_k[1] = o; o += up(4 * R);
+    p.off_v[0] = o; o += up(4 * R);
+    p.off_v[1] = o; if (p.passes >= 3) o += up(4 * R);
+    p.off_hist = o; o += up(4 * p.ntiles * ((size_t)1 << p.width));
+    p.off_tot = o; o += up(4 * TG_BINS);
+    p.bytes = o;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t gs4d_transpose_graph_scratch_bytes(int n, long long pairs)
+{
+    if (n < 1 || pairs < 1) return 0;
+    return tg_plan(n, (size_t)pairs).bytes;
+}
+
+extern "C" int gs4d_transpose_graph(int n, long long pairs, const int* idx, int* order, int* row_start, void* scratch,
+                                    size_t scratch_bytes, void* stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    if (n < 1 || pairs < 1 || pairs > 0x7fffffffll) { gs4d_set_error("gs4d_transpose_graph: need n >= 1 and 1 <= pairs < 2^31"); return GS4D_EINVAL; }
+    if (!idx || !order || !row_start || !scratch || ((uintptr_t)scratch & 255)) {
+        gs4d_set_error("gs4d_transpose_graph: null pointer, or scratch not 256-byte aligned");
+        return GS4D_EINVAL;
+    }
+    const TgPlan p = tg_plan(n, (size_t)pairs);
+    if (scratch_bytes < p.bytes) { gs4d_set_error("gs4d_transpose_graph: scratch smaller than gs4d_transpose_graph_scratch_bytes(n, pairs)"); return GS4D_EINVAL; }
+    char* base = (char*)scratch;
+    uint32_t* kbuf[2] = {(uint32_t*)(base + p.off_k[0]), (uint32_t*)(base + p.off_k[1])};
+    uint32_t* vbuf[2] = {(uint32_t*)(base + p.off_v[0]), (uint32_t*)(base + p.off_v[1])};
+    uint32_t* hist = (uint32_t*)(base + p.off_hist);
+    uint32_t* totals = (uint32_t*)(base + p.off_tot);
+    const uint32_t R = (uint32_t)pairs, nt = (uint32_t)p.ntiles;
+    GS4D_PROF("transpose_graph", s);
+    const uint32_t* kin = (const uint32_t*)idx;
+    const uint32_t* vin = nullptr;
+    for (int q = 0; q < p.passes; q++) {
+        const int shift = q * p.width;
+        uint32_t* kout = kbuf[q & 1];
+        uint32_t* vout = q == p.passes - 1 ? (uint32_t*)order : vbuf[q & 1];
+        hipLaunchKernelGGL(tg_hist_kernel, dim3(nt), dim3(TG_THREADS), 0, s, R, shift, p.width, kin, hist, nt);
+        hipLaunchKernelGGL(tg_scan_kernel, dim3(1u << p.width), dim3(256), 0, s, nt, hist, totals);
+        if (q == 0)
+            hipLaunchKernelGGL(tg_scatter_kernel<true>, dim3(nt), dim3(TG_THREADS), 0, s, R, shift, p.width, kin, vin, kout, vout, hist, totals, nt);
+        else
+            hipLaunchKernelGGL(tg_scatter_kernel<false>, dim3(nt), dim3(TG_THREADS), 0, s, R, shift, p.width, kin, vin, kout, vout, hist, totals, nt);
+        kin = kout; vin = vout;
+    }
+    hipLaunchKernelGGL(tg_bounds_kernel, dim3((R + 1 + 255) / 256), dim3(256), 0, s, R, n, kin, row_start);
+    GS4D_LAUNCH_CHECK("transpose_graph", 0, s);
+    return GS4D_OK;
+}

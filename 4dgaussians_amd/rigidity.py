@@ -18,8 +18,8 @@ from .pointops import knn, knn_self_i32
 
 def transpose_graph(idx: torch.Tensor, trusted: bool = False):
     """idx (..., n, k) -> (order int32 [n*k], row_start int32 [n+1]): the pairs i*k+s sorted by their target idx[i][s]
-    and where each target's pairs begin.  Built once per neighbour graph (one device sort, shared by every term of a
-    view); it turns the backward's scatter into a gather.  trusted=True skips the range check of the indices (two
+    and where each target's pairs begin.  Built once per neighbour graph (gs4d_transpose_graph: a radix sort over the bits the targets have, shared by every
+    term of a view); it turns the backward's scatter into a gather.  trusted=True skips the range check of the indices (two
     reductions and two host synchronisations per view): for lists that come straight out of this package's knn()."""
     n, k = idx.shape[-2], idx.shape[-1]
     if n * k >= 2 ** 31:
@@ -27,10 +27,24 @@ def transpose_graph(idx: torch.Tensor, trusted: bool = False):
     flat = idx.reshape(-1).to(torch.int32)
     if not trusted and flat.numel() and (int(flat.min()) < 0 or int(flat.max()) >= n):
         raise RuntimeError("transpose_graph: neighbour index out of range")
-    targets, order = torch.sort(flat)
-    # where each target's run begins in the sorted list (a bincount + cumsum costs more than the sort itself)
-    row_start = torch.searchsorted(targets, torch.arange(n + 1, dtype=torch.int32, device=idx.device)).to(torch.int32)
-    return order.to(torch.int32), row_start
+    flat = flat.contiguous()
+    if flat.device.type != "cuda":
+        raise RuntimeError("transpose_graph needs the neighbour lists on a HIP device; there is no CPU path")
+    L = _cabi.lib()
+    R = flat.numel()
+    order = torch.empty(R, dtype=torch.int32, device=flat.device)
+    row_start = torch.empty(n + 1, dtype=torch.int32, device=flat.device)
+    if R == 0:
+        return order, row_start.zero_()
+    L.gs4d_transpose_graph_scratch_bytes.restype = C.c_size_t
+    nbytes = int(L.gs4d_transpose_graph_scratch_bytes(C.c_int(n), C.c_longlong(R)))
+    scratch = torch.empty(nbytes + 256, dtype=torch.uint8, device=flat.device)
+    sp = (scratch.data_ptr() + 255) & ~255
+    with torch.cuda.device(flat.device):
+        rc = L.gs4d_transpose_graph(C.c_int(n), C.c_longlong(R), _cabi.ptr(flat), _cabi.ptr(order), _cabi.ptr(row_start),
+                                    C.c_void_p(sp), C.c_size_t(nbytes), _cabi.current_stream(flat.device))
+    _cabi.check(rc, "transpose_graph")
+    return order, row_start
 
 
 class _NeighborDiffNorm(torch.autograd.Function):

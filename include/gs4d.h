@@ -406,6 +406,17 @@ int gs4d_neighbor_diff_norm_backward_gather(int n, int k, int dim, const float* 
                                             const float* g, const int* order, const int* row_start, float* coef_scratch,
                                             float* dx, void* stream);
 
+/* The transposed neighbour graph those gather backwards read, built on the device: idx [pairs] int32 with values in
+ * [0, n) (pairs = n*k for one graph; the lists as gs4d_knn_query writes them) -> order [pairs] = the pair indices sorted by
+ * idx[pair], ascending pair index inside one target (a stable sort: the result is unique), row_start [n+1] = first position
+ * in `order` of each target's pairs (row_start[n] = pairs).  The reference scatters through autograd's index_put
+ * (gaussian_renderer/renderer.py:163-165,194-203: vel[idx] / rot[idx]); there is no counterpart call.  Indices are NOT
+ * range-checked (an index >= n sorts somewhere, writes nothing out of bounds).  scratch: 256-byte aligned,
+ * gs4d_transpose_graph_scratch_bytes(n, pairs) bytes, free again when the stream has run the call.  1 <= pairs < 2^31. */
+size_t gs4d_transpose_graph_scratch_bytes(int n, long long pairs);
+int gs4d_transpose_graph(int n, long long pairs, const int* idx, int* order, int* row_start, void* scratch,
+                         size_t scratch_bytes, void* stream);
+
 /* The three kNN terms of the fine stage's temporal branch (gaussian_renderer/renderer.py:189-203) fused: forward ->
  * sums4 = (S_xyz, S_long, S_rot, S_w) with w = exp(-100 dist) (definitions in csrc/rigidity.hip; knn_xyz = S_xyz/k/n,
  * knn_long = S_long/k/n, knn_rot = S_rot/(n k) * S_w/k/n); backward -> gradients of the four fields given coef3 =

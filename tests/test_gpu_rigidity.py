@@ -78,6 +78,35 @@ def test_neighbor_diff_norm_edge_cases():
         rig.neighbor_diff_norm(torch.zeros(4, 3), torch.zeros(1, 4, 2, dtype=torch.int64))     # CPU tensors: no CPU path
 
 
+@pytest.mark.parametrize("n,k,skew", [(1, 1, False), (5, 2, False), (513, 7, True), (700, 100, False), (100_000, 30, False),
+                                      (131_073, 9, True), (300_000, 8, True)],
+                         ids=["one", "tiny", "two_narrow_passes", "one_wide_pass_pair", "c2_bits", "just_over_17_bits", "three_passes"])
+def test_transpose_graph_is_the_stable_sort(n, k, skew):
+    """gs4d_transpose_graph against torch.sort(stable=True) of the targets: order and row_start bit for bit (the stable
+    permutation is unique).  skew: most pairs point at a few targets and many targets have no pair at all; the sizes
+    cover one, two and three digit passes, a last tile that is not full and digits narrower than nine bits."""
+    rig = pkg("rigidity")
+    g = torch.Generator().manual_seed(n + k)
+    if skew:
+        hubs = torch.randint(0, n, (max(n // 50, 1),), generator=g)
+        idx = hubs[torch.randint(0, hubs.numel(), (n, k), generator=g)]
+        idx[::3] = torch.randint(0, n, idx[::3].shape, generator=g)
+        idx[0, 0] = n - 1
+    else:
+        idx = torch.randint(0, n, (n, k), generator=g)
+    idx = idx.to(torch.int32).cuda()
+    order, row_start = rig.transpose_graph(idx[None], trusted=True)
+    flat = idx.reshape(-1).long()
+    want_t, want_o = torch.sort(flat, stable=True)
+    assert order.dtype == torch.int32 and order.shape == (n * k,)
+    assert torch.equal(order.long(), want_o)
+    want_rs = torch.searchsorted(want_t, torch.arange(n + 1, device="cuda"))
+    assert row_start.dtype == torch.int32 and torch.equal(row_start.long(), want_rs)
+    # a second call on the same stream reuses the allocator's blocks: same answer
+    order2, row_start2 = rig.transpose_graph(idx[None], trusted=True)
+    assert torch.equal(order2, order) and torch.equal(row_start2, row_start)
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_terms", "composed"])
 def test_temporal_regulation_matches_reference_expressions(fused):
     rig = pkg("rigidity")
