@@ -679,7 +679,9 @@ extern "C" int gs4d_temporal_regulation_backward(int n, int k, int sh_floats, co
 namespace {
 
 #define TG_THREADS 256
+#ifndef TG_ITEMS
 #define TG_ITEMS 8
+#endif
 #define TG_TILE (TG_THREADS * TG_ITEMS)
 #define TG_BINS 512
 
