@@ -205,7 +205,7 @@ static int sort_passes(int W, int H)
 extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
-int gs4d_abi_version(void) { return 8; }
+int gs4d_abi_version(void) { return 9; }
 
 void gs4d_thread_state_release(void)
 {

@@ -555,6 +555,12 @@ extern "C" int gs4d_knn_mean_dist2_static(int P, const float* points, float* mea
 extern "C" int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,
                               int nsample, int* idx, float* dist2, void* stream)
 {
+    return gs4d_knn_query_order(alloc, alloc_ctx, n, xyz, m, new_xyz, nsample, idx, dist2, nullptr, stream);
+}
+
+extern "C" int gs4d_knn_query_order(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,
+                                    int nsample, int* idx, float* dist2, int* point_order, void* stream)
+{
     hipStream_t s = (hipStream_t)stream;
     if (m == 0) return GS4D_OK;
     if (n <= 0 || m < 0 || !xyz || !idx || !dist2 || !alloc || nsample < 1 || nsample > KQ_MAXK) {
@@ -598,6 +604,7 @@ extern "C" int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const
     int rc = gs4d_radix_sort_pairs((uint32_t)n, 4, 0, codes, ids, ktmp, vtmp, hist, &where, 0, s);
     if (rc) return rc;
     hipLaunchKernelGGL(kq_gather_box_kernel, dim3(nboxes), dim3(KQ_BOX), 0, s, n, xyz, vtmp[where], sorted, boxes);
+    if (point_order) GS4D_HIP_CHECK(hipMemcpyAsync(point_order, vtmp[where], sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(kq_super_box_kernel, dim3(nsuper), dim3(64), 0, s, nboxes, boxes, supers);
     int idbits = 1;
     while (idbits < 32 && ((unsigned)(n - 1) >> idbits)) idbits++;

@@ -13,9 +13,11 @@ import torch
 from . import _cabi
 
 
-def knnquery(nsample, xyz, new_xyz, offset, new_offset):
+def knnquery(nsample, xyz, new_xyz, offset, new_offset, _point_order=None):
     """input: xyz (n, 3), new_xyz (m, 3) or None, offset (b) / new_offset (b): cumulative batch ends.
-    output: idx int32 (m, nsample) -- indices into xyz --, dist float32 (m, nsample) = sqrt(dist2), ascending."""
+    output: idx int32 (m, nsample) -- indices into xyz --, dist float32 (m, nsample) = sqrt(dist2), ascending.
+    _point_order (not in the reference; single batch only): an int32 tensor (n,) that receives the points' indices in
+    Morton order (gs4d_knn_query_order)."""
     if new_xyz is None:
         new_xyz = xyz
     if xyz.device.type != "cuda" or new_xyz.device.type != "cuda":
@@ -38,6 +40,9 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
     idx = make((m, nsample), dtype=torch.int32, device=dev)
     dist2 = make((m, nsample), dtype=torch.float32, device=dev)
     same = new_xyz is xyz or (new_xyz.data_ptr() == xyz.data_ptr() and new_xyz.shape == xyz.shape)
+    if _point_order is not None and (len(ends) != 1 or _point_order.shape != (ends[0],) or _point_order.dtype != torch.int32
+                                     or not _point_order.is_contiguous() or _point_order.device != dev):
+        raise RuntimeError("knnquery: _point_order needs one batch and a contiguous int32 tensor of n entries on the points' device")
     start = qstart = 0
     for end, qend in zip(ends, qends):
         n_b, m_b = end - start, qend - qstart
@@ -48,10 +53,12 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
             qs = new_xyz[qstart:qend]
             scratch = _cabi.TensorAllocator(dev)
             with torch.cuda.device(dev):
-                rc = L.gs4d_knn_query(scratch.callback, scratch.ctx, C.c_int(n_b), _cabi.ptr(pts), C.c_int(m_b),
-                                      C.c_void_p(0) if (same and start == qstart) else _cabi.ptr(qs), C.c_int(int(nsample)),
-                                      C.c_void_p(idx.data_ptr() + 4 * qstart * nsample),
-                                      C.c_void_p(dist2.data_ptr() + 4 * qstart * nsample), _cabi.current_stream(dev))
+                rc = L.gs4d_knn_query_order(scratch.callback, scratch.ctx, C.c_int(n_b), _cabi.ptr(pts), C.c_int(m_b),
+                                            C.c_void_p(0) if (same and start == qstart) else _cabi.ptr(qs), C.c_int(int(nsample)),
+                                            C.c_void_p(idx.data_ptr() + 4 * qstart * nsample),
+                                            C.c_void_p(dist2.data_ptr() + 4 * qstart * nsample),
+                                            _cabi.ptr(_point_order) if _point_order is not None else C.c_void_p(0),
+                                            _cabi.current_stream(dev))
             scratch.close()
             _cabi.check(rc, "gs4d_knn_query")
             if start:
@@ -60,13 +67,17 @@ def knnquery(nsample, xyz, new_xyz, offset, new_offset):
     return idx, torch.sqrt(dist2)
 
 
-def knn_self_i32(points, k):
+def knn_self_i32(points, k, return_order=False):
     """The render path's query: the k nearest neighbours of every row of points (n, 3) among the same rows ->
     idx int32 (n, k) exactly as gs4d_knn_query writes it, dist float32 (n, k).  What knn() does for one batch, without
-    the offset arithmetic and the widening to int64 (two passes over the 10 M-entry lists at C2)."""
+    the offset arithmetic and the widening to int64 (two passes over the 10 M-entry lists at C2).  return_order: also the
+    points' indices in Morton order, int32 (n,) -- the row order the regulariser kernels visit the lists in."""
     n = points.shape[0]
     off = torch.tensor([n], dtype=torch.int32)
-    return knnquery(int(k), points, points, off, off)
+    if not return_order:
+        return knnquery(int(k), points, points, off, off)
+    order = torch.empty(n, dtype=torch.int32, device=points.device)
+    return (*knnquery(int(k), points, points, off, off, _point_order=order), order)
 
 
 def knn(x, src, k, transpose=False):

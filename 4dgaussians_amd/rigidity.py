@@ -168,7 +168,7 @@ class _TemporalRegulation(torch.autograd.Function):
             if ins[i].data_ptr() % 16:
                 ins[i] = ins[i].clone()
         shf = ins[7].numel() // n
-        idx, dist = knn_self_i32(ins[1], k)                  # neighbours of means3D_final (renderer.py:192)
+        idx, dist, row_order = knn_self_i32(ins[1], k, return_order=True)   # neighbours of means3D_final (renderer.py:192)
         order, row_start = transpose_graph(idx, trusted=True)
         L = _cabi.lib()
         L.gs4d_temporal_regulation_scratch_bytes.restype = C.c_size_t
@@ -180,13 +180,13 @@ class _TemporalRegulation(torch.autograd.Function):
             rc = L.gs4d_temporal_regulation_forward(C.c_int(n), C.c_int(k), C.c_int(shf), ptrs, _cabi.ptr(idx), _cabi.ptr(dist),
                                                     _cabi.ptr(packed), _cabi.ptr(scratch), _cabi.ptr(out), _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_temporal_regulation_forward")
-        ctx.save_for_backward(*ins, idx, dist, order, row_start, packed, scratch)
+        ctx.save_for_backward(*ins, idx, dist, order, row_start, row_order, packed, scratch)
         ctx.k, ctx.shf, ctx.shapes = k, shf, [t.shape for t in t13]
         return out
 
     @staticmethod
     def backward(ctx, g):
-        *ins, idx, dist, order, row_start, packed, scratch = ctx.saved_tensors
+        *ins, idx, dist, order, row_start, row_order, packed, scratch = ctx.saved_tensors
         n, dev = ins[1].shape[0], ins[1].device
         g_ = g.to(torch.float32).contiguous()
         grads = [torch.empty_like(t) for t in ins]
@@ -195,7 +195,8 @@ class _TemporalRegulation(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = _cabi.lib().gs4d_temporal_regulation_backward(
                 C.c_int(n), C.c_int(ctx.k), C.c_int(ctx.shf), ip, _cabi.ptr(idx), _cabi.ptr(dist), _cabi.ptr(order),
-                _cabi.ptr(row_start), _cabi.ptr(packed), _cabi.ptr(scratch), _cabi.ptr(g_), gp, _cabi.current_stream(dev))
+                _cabi.ptr(row_start), _cabi.ptr(row_order), _cabi.ptr(packed), _cabi.ptr(scratch), _cabi.ptr(g_), gp,
+                _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_temporal_regulation_backward")
         return (None, *[gr.view(sh) for gr, sh in zip(grads, ctx.shapes)])
 

@@ -216,6 +216,11 @@ int gs4d_knn_mean_dist2_static(int P, const float* points, float* mean_dist2, vo
  */
 int gs4d_knn_query(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,
                    int nsample, int* idx, float* dist2, void* stream);
+/* The same query; point_order [n] int32 (may be NULL) receives the indices of the n points of xyz in the order of their
+ * Morton codes, which the query builds anyway: rows visited in that order touch neighbouring points' records while they
+ * are still in cache (gs4d_temporal_regulation_* take it as row_order).  No counterpart in the reference. */
+int gs4d_knn_query_order(gs4d_alloc_fn alloc, void* alloc_ctx, int n, const float* xyz, int m, const float* new_xyz,
+                         int nsample, int* idx, float* dist2, int* point_order, void* stream);
 
 /*
  * HexPlane deformation field.  The reference implements it in PyTorch
@@ -449,13 +454,17 @@ int gs4d_rigidity_terms_backward_i32(int n, int k, const float* packed, const in
  * prev / next [n,4] (16-byte aligned).  idx [n,k] int32 and dist [n,k]: the k nearest neighbours of means3D_final
  * (gs4d_knn_query; dist carries no gradient); order / row_start: the transposed neighbour graph as for
  * gs4d_rigidity_terms_backward.  packed [n][16] floats and scratch (gs4d_temporal_regulation_scratch_bytes(n), 16-byte
- * aligned) are written by the forward and read by the backward.  Gradients are written in full, deterministic. */
+ * aligned) are written by the forward and read by the backward.  Gradients are written in full, deterministic.
+ * row_order [n] (may be NULL = 0, 1, 2, ...): a PERMUTATION of the rows, the order the backward visits them in; the point
+ * order of gs4d_knn_query_order keeps neighbouring rows' records in cache.  It changes no result (each row's sums run in
+ * the same order either way). */
 size_t gs4d_temporal_regulation_scratch_bytes(int n);
 int gs4d_temporal_regulation_forward(int n, int k, int sh_floats, const float* const* in13, const int* idx,
                                      const float* dist, float* packed, float* scratch, float* out6, void* stream);
 int gs4d_temporal_regulation_backward(int n, int k, int sh_floats, const float* const* in13, const int* idx,
-                                      const float* dist, const int* order, const int* row_start, const float* packed,
-                                      float* scratch, const float* g6, float* const* grad13, void* stream);
+                                      const float* dist, const int* order, const int* row_start, const int* row_order,
+                                      const float* packed, float* scratch, const float* g6, float* const* grad13,
+                                      void* stream);
 
 #ifdef __cplusplus
 }

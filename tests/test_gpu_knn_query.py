@@ -79,3 +79,19 @@ def test_knn_query_argument_errors():
         P.knnquery(129, x, None, off, off)
     with pytest.raises(RuntimeError, match="HIP device"):
         P.knnquery(3, x.cpu(), None, off, off)
+
+
+def test_point_order_is_a_permutation_and_changes_no_list():
+    """gs4d_knn_query_order: the Morton order of the points comes back as a permutation; lists and distances are those of
+    the plain query, bit for bit."""
+    po = pkg("pointops")
+    g = torch.Generator().manual_seed(5)
+    pts = torch.randn(5000, 3, generator=g).cuda()
+    idx0, d0 = po.knn_self_i32(pts, 20)
+    idx1, d1, order = po.knn_self_i32(pts, 20, return_order=True)
+    assert torch.equal(idx0, idx1) and torch.equal(d0, d1)
+    assert order.dtype == torch.int32 and order.shape == (5000,)
+    assert torch.equal(torch.sort(order.long()).values, torch.arange(5000, device="cuda"))
+    # spatially coherent: consecutive points of the order are far closer than consecutive points of the input
+    step = lambda p: float((p[1:] - p[:-1]).norm(dim=1).mean())
+    assert step(pts[order.long()]) < 0.5 * step(pts)

@@ -12,6 +12,15 @@ dev = torch.device("cuda")
 _, cam0, raw = syn.make_workload("C2")
 torch.manual_seed(syn.seed_for("C2"))
 raw = dict(raw, log_scales=raw["log_scales"] + 0.4982)
+if os.environ.get("FFS_MORTON"):      # experiment: Gaussians stored in Morton order of their positions
+    import numpy as np
+    x = np.asarray(raw["xyz"], dtype=np.float64)
+    q = ((x - x.min(0)) / (x.max(0) - x.min(0) + 1e-12) * 1023).astype(np.uint64)
+    def spread(v):
+        v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; return (v | (v << 2)) & 0x09249249
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
+    o = np.argsort(code, kind="stable")
+    raw = {k_: (v_[o] if hasattr(v_, "shape") and len(v_) == len(o) else v_) for k_, v_ in raw.items()}
 pc = R.GaussianParams(raw, dev)
 Wl = importlib.import_module("4dgaussians_amd.workload")
 deform = Dm.deform_network(Wl.deform_args("C2")); deform.deformation_net.set_aabb([1.3] * 3, [-1.3] * 3); deform = deform.to(dev)
