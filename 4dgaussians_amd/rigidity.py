@@ -182,13 +182,21 @@ class _TemporalRegulation(torch.autograd.Function):
         _cabi.check(rc, "gs4d_temporal_regulation_forward")
         ctx.save_for_backward(*ins, idx, dist, order, row_start, row_order, packed, scratch)
         ctx.k, ctx.shf, ctx.shapes = k, shf, [t.shape for t in t13]
-        return out
+        # six scalars, not one tensor for the caller to index: every out[i] in a loss expression costs the backward a
+        # zero-filled [6] tensor, an index copy and an add (17 tiny kernels per iteration for the six terms)
+        ctx.set_materialize_grads(False)
+        return tuple(out.unbind(0))
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         *ins, idx, dist, order, row_start, row_order, packed, scratch = ctx.saved_tensors
         n, dev = ins[1].shape[0], ins[1].device
-        g_ = g.to(torch.float32).contiguous()
+        if all(g is None for g in gs):
+            return (None,) * 14
+        zero = None
+        if any(g is None for g in gs):
+            zero = torch.zeros((), dtype=torch.float32, device=dev)
+        g_ = torch.stack([zero if g is None else g.to(torch.float32).reshape(()) for g in gs]).contiguous()
         grads = [torch.empty_like(t) for t in ins]
         ip = (C.c_void_p * 13)(*[t.data_ptr() for t in ins])
         gp = (C.c_void_p * 13)(*[t.data_ptr() for t in grads])
@@ -221,8 +229,8 @@ def temporal_regulation(means3D, means3D_final, means3D_prev, means3D_nxt, scale
         n = means3D_final.shape[0]
         out = _TemporalRegulation.apply(min(int(k), n), means3D, means3D_final, means3D_prev, means3D_nxt, scales_final, scales_prev,
                                         scales_nxt, shs_final, shs_prev, shs_nxt, rotations_final, rotations_prev, rotations_next)
-        for i, name in enumerate(("momentum", "scales", "shs", "knn_xyz", "knn_long", "knn_rot")):
-            reg[name] = out[i]
+        for name, term in zip(("momentum", "scales", "shs", "knn_xyz", "knn_long", "knn_rot"), out):
+            reg[name] = term
         return reg
     momentum_all = torch.abs(means3D_nxt + means3D_prev - 2 * means3D_final)
     reg["momentum"] = momentum_all.mean()

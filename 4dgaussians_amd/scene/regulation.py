@@ -25,6 +25,9 @@ class PlaneRegTerm(C.Structure):
                 ("kind", C.c_int), ("weight", C.c_float)]
 
 
+_TERM_CACHE = {}
+
+
 class _PlaneReg(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kinds_weights, *planes):
@@ -34,10 +37,18 @@ class _PlaneReg(torch.autograd.Function):
         if dev.type != "cuda":
             raise RuntimeError("the plane regularisers run on a HIP device only; there is no CPU path")
         mem = [p.detach().contiguous(memory_format=torch.channels_last) for p in planes]
-        terms = (PlaneRegTerm * len(kinds_weights))()
-        for t, (i, kind, w) in zip(terms, kinds_weights):
-            p = mem[i]
-            t.plane, t.grad, t.C, t.H, t.W, t.kind, t.weight = p.data_ptr(), None, p.shape[1], p.shape[2], p.shape[3], kind, w
+        # the term table only depends on where the planes live and on the weights: filled once, not on every step (24 terms
+        # x 7 ctypes fields, twice per iteration, were a quarter of a millisecond of host time)
+        key = (kinds_weights, tuple(p.data_ptr() for p in mem), tuple(p.shape for p in mem))
+        terms = _TERM_CACHE.get(key)
+        if terms is None:
+            terms = (PlaneRegTerm * len(kinds_weights))()
+            for t, (i, kind, w) in zip(terms, kinds_weights):
+                p = mem[i]
+                t.plane, t.grad, t.C, t.H, t.W, t.kind, t.weight = p.data_ptr(), None, p.shape[1], p.shape[2], p.shape[3], kind, w
+            if len(_TERM_CACHE) >= 8:
+                _TERM_CACHE.clear()
+            _TERM_CACHE[key] = terms
         nscratch = int(L.gs4d_plane_reg_scratch_bytes()) // 4
         buf = torch.empty(nscratch, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)       # its own tensor: callers do `loss += reg`
@@ -45,7 +56,7 @@ class _PlaneReg(torch.autograd.Function):
             rc = L.gs4d_plane_reg_forward(C.c_int(len(kinds_weights)), terms, _cabi.ptr(buf), _cabi.ptr(loss),
                                           _cabi.current_stream(dev))
         _cabi.check(rc, "gs4d_plane_reg_forward")
-        ctx.kinds_weights = kinds_weights
+        ctx.kinds_weights, ctx.terms = kinds_weights, terms
         ctx.save_for_backward(*mem)
         return loss
 
@@ -59,9 +70,10 @@ class _PlaneReg(torch.autograd.Function):
         flat = _cabi.zeros_group(dev, *shapes)
         grads = {i: t for i, t in zip(used, flat)}
         terms = (PlaneRegTerm * len(ctx.kinds_weights))()
-        for t, (i, kind, w) in zip(terms, ctx.kinds_weights):
-            p = mem[i]
-            t.plane, t.grad, t.C, t.H, t.W, t.kind, t.weight = p.data_ptr(), grads[i].data_ptr(), p.shape[1], p.shape[2], p.shape[3], kind, w
+        C.memmove(terms, ctx.terms, C.sizeof(terms))                  # a private copy of the forward's table + the gradient pointers
+        gptr = {i: t.data_ptr() for i, t in grads.items()}
+        for t, (i, _, _) in zip(terms, ctx.kinds_weights):
+            t.grad = gptr[i]
         g_ = g.reshape(1).to(torch.float32).contiguous()
         with torch.cuda.device(dev):
             rc = L.gs4d_plane_reg_backward(C.c_int(len(ctx.kinds_weights)), terms, _cabi.ptr(g_), _cabi.current_stream(dev))

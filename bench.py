@@ -427,7 +427,7 @@ def main():
             full_step()
         sync()
         t0 = time.perf_counter()
-        nfull = max(3, args.steps // 3)
+        nfull = max(3, args.steps)
         for _ in range(nfull):
             full_step()
         sync()

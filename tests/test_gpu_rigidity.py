@@ -107,6 +107,26 @@ def test_transpose_graph_is_the_stable_sort(n, k, skew):
     assert torch.equal(order2, order) and torch.equal(row_start2, row_start)
 
 
+def test_temporal_regulation_loss_of_two_terms_only():
+    """A loss that names only some of the six terms (the fused Function then receives no gradient for the others): the
+    gradients equal those of the composed, line-by-line path."""
+    rig = pkg("rigidity")
+    n, k = 400, 20
+    base = _scene(n, 11)
+    grads = {}
+    for fused in (True, False):
+        dev = {a: v.detach().clone().cuda().requires_grad_(True) for a, v in base.items()}
+        got = rig.temporal_regulation(*[dev[a] for a in NAMES], k=k, fused=fused)
+        (got["knn_xyz"] + 2.0 * got["shs"]).backward()
+        grads[fused] = {a: (torch.zeros_like(dev[a]) if dev[a].grad is None else dev[a].grad.clone()) for a in NAMES}
+    for a in NAMES:
+        scale = float(grads[False][a].abs().max())
+        assert float((grads[True][a] - grads[False][a]).abs().max()) <= 2e-5 * scale + 1e-12, a
+    dev = {a: v.detach().clone().cuda().requires_grad_(True) for a, v in base.items()}
+    got = rig.temporal_regulation(*[dev[a] for a in NAMES], k=k, fused=True)
+    assert all(got[t].dim() == 0 for t in ("momentum", "scales", "shs", "knn_xyz", "knn_long", "knn_rot"))
+
+
 @pytest.mark.parametrize("fused", [True, False], ids=["fused_terms", "composed"])
 def test_temporal_regulation_matches_reference_expressions(fused):
     rig = pkg("rigidity")
