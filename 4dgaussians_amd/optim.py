@@ -50,7 +50,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
-        self._sig = None                                   # new state tensors, new step counts
+        self._sig, self._plan = None, None                 # new state tensors, new step counts
 
     def add_param_group(self, param_group):
         super().add_param_group(param_group)
@@ -81,9 +81,14 @@ class FusedAdamW(torch.optim.Optimizer):
         for key, items in batches.items():
             rec = np.zeros(len(items), dtype=_REC)
             rec["numel"] = [p.numel() for _, p, _ in items]
+            # the `step` entries of the torch state layout become zero-dim views of ONE tensor per batch: a single add
+            # per step keeps all of them current (an add on each of 60 separate tensors was 70 us of host time)
+            counts = [float(st["step"]) for _, _, st in items]
+            base = torch.tensor(counts, dtype=torch.float32)
+            for i, (_, _, st) in enumerate(items):
+                st["step"] = base[i]
             plan.append(dict(key=key, items=items, rec=rec, gidx=np.array([gi for gi, _, _ in items]),
-                             steps=np.array([float(st["step"]) for _, _, st in items], dtype=np.float64),
-                             step_tensors=[st["step"] for _, _, st in items]))
+                             steps=np.array(counts, dtype=np.float64), base=base))
         return plan
 
     @torch.no_grad()
@@ -118,11 +123,16 @@ class FusedAdamW(torch.optim.Optimizer):
                 pp.append(p.data_ptr()); gp.append(g.data_ptr()); mp.append(m.data_ptr()); vp.append(v.data_ptr())
             rec["param"], rec["grad"], rec["exp_avg"], rec["exp_avg_sq"] = pp, gp, mp, vp
             rec["lr"], rec["weight_decay"] = lrs[b["gidx"]], wds[b["gidx"]]
-            b["steps"] += 1.0
-            torch._foreach_add_(b["step_tensors"], 1.0)
-            vals, inv = np.unique(b["steps"], return_inverse=True)          # one value unless parameters joined later
-            rec["bias_correction1"] = np.array([1.0 - beta1 ** float(x) for x in vals])[inv]
-            rec["bias_correction2"] = np.array([1.0 - beta2 ** float(x) for x in vals])[inv]
+            steps = b["steps"]
+            steps += 1.0
+            b["base"] += 1.0
+            if steps[0] == steps[-1] and (steps == steps[0]).all():         # one value unless parameters joined later
+                rec["bias_correction1"] = 1.0 - beta1 ** float(steps[0])
+                rec["bias_correction2"] = 1.0 - beta2 ** float(steps[0])
+            else:
+                vals, inv = np.unique(steps, return_inverse=True)
+                rec["bias_correction1"] = np.array([1.0 - beta1 ** float(x) for x in vals])[inv]
+                rec["bias_correction2"] = np.array([1.0 - beta2 ** float(x) for x in vals])[inv]
             with torch.cuda.device(dev):
                 rc = L.gs4d_adamw_step(C.c_int(len(rec)), C.c_void_p(rec.ctypes.data), C.c_double(beta1), C.c_double(beta2),
                                        C.c_double(eps), _cabi.current_stream(dev))

@@ -97,6 +97,29 @@ def plane_regulation(planes, kinds_weights):
     return total
 
 
+_EVERY_CACHE = {}
+
+
+def _every_terms(index, args, time_smoothness_weight, l1_time_planes_weight, l2_time_planes_weight, plane_tv_weight):
+    def terms(grid_ids, kind, weight):
+        return [(index[(lv, gi)], int(kind), float(weight)) for (lv, gi) in index if gi in grid_ids]
+    every = terms(PLANE_GRIDS, SMOOTHNESS, plane_tv_weight) if plane_tv_weight > 1e-7 else []
+    if args.use_time:
+        every += terms(TIME_GRIDS, SMOOTHNESS, time_smoothness_weight) if time_smoothness_weight > 1e-7 else []
+        every += terms(TIME_GRIDS, L1, l1_time_planes_weight) if l1_time_planes_weight > 1e-7 else []
+        every += terms(TIME_GRIDS, L2, l2_time_planes_weight) if l2_time_planes_weight > 1e-7 else []
+    return tuple(every)
+
+
+def _plane_regulation_checked(planes, kinds_weights):
+    """plane_regulation for a term tuple that already holds (int, int, float) entries."""
+    total = None
+    for lo in range(0, len(kinds_weights), MAX_TERMS):
+        part = _PlaneReg.apply(kinds_weights[lo:lo + MAX_TERMS], *planes)
+        total = part if total is None else total + part
+    return total
+
+
 def compute_plane_smoothness(t):
     """scene/regulation.py:22-29."""
     return plane_regulation([t], [(0, SMOOTHNESS, 1.0)])
@@ -118,6 +141,16 @@ def compute_regulation(deformation, time_smoothness_weight, l1_time_planes_weigh
         for gi, p in enumerate(grids):
             index[(lv, gi)] = len(planes)
             planes.append(p)
+    if not detail:                         # the training loop's call: the same term list on every iteration
+        key = (tuple(index), bool(args.use_time), float(time_smoothness_weight), float(l1_time_planes_weight),
+               float(l2_time_planes_weight), float(plane_tv_weight))
+        every = _EVERY_CACHE.get(key)
+        if every is None:
+            every = _every_terms(index, args, time_smoothness_weight, l1_time_planes_weight, l2_time_planes_weight, plane_tv_weight)
+            _EVERY_CACHE[key] = every
+        out = defaultdict(lambda: torch.tensor(0))
+        out["total_reg"] = _plane_regulation_checked(planes, every) if every else torch.tensor(0)
+        return out
 
     def terms(grid_ids, kind, weight):
         return [(index[(lv, gi)], kind, weight) for (lv, gi) in index if gi in grid_ids]

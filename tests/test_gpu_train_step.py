@@ -135,3 +135,35 @@ def test_plane_regulation_matches_reference_expressions(multires):
     # the single-plane helper of scene/regulation.py
     t = torch.rand(1, 8, 3, 5, device="cuda").contiguous(memory_format=torch.channels_last)
     assert abs(float(reg.compute_plane_smoothness(t)) - float(ref_smoothness(t.cpu().double()))) <= 1e-6
+
+
+def test_adamw_step_counts_survive_state_dict_round_trip():
+    """The step counts are kept outside the `step` tensors between steps: state_dict() shows the true count, and an
+    optimizer restored from it continues exactly like the original."""
+    om = pkg("optim")
+    g = torch.Generator().manual_seed(3)
+    mk = lambda: [torch.nn.Parameter(torch.randn(33, 8, generator=g).cuda()), torch.nn.Parameter(torch.randn(64, generator=g).cuda())]
+    pa = mk()
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    grads = [[torch.randn(p.shape, generator=g).cuda() for p in pa] for _ in range(5)]
+    oa = om.FusedAdamW([{"params": pa[:1], "lr": 1e-2}, {"params": pa[1:], "lr": 3e-3}])
+    ob = om.FusedAdamW([{"params": pb[:1], "lr": 1e-2}, {"params": pb[1:], "lr": 3e-3}])
+    for it in range(3):
+        for opt, ps in ((oa, pa), (ob, pb)):
+            for p, gr in zip(ps, grads[it]):
+                p.grad = gr.clone()
+            opt.step()
+    sd = oa.state_dict()
+    assert all(float(st["step"]) == 3.0 for st in sd["state"].values())
+    assert all(float(oa.state[p]["step"]) == 3.0 for p in pa)
+    pc = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oc = om.FusedAdamW([{"params": pc[:1], "lr": 1e-2}, {"params": pc[1:], "lr": 3e-3}])
+    oc.load_state_dict(sd)
+    for it in range(3, 5):
+        for opt, ps in ((ob, pb), (oc, pc)):
+            for p, gr in zip(ps, grads[it]):
+                p.grad = gr.clone()
+            opt.step()
+    for b_, c_ in zip(pb, pc):
+        assert torch.equal(b_, c_)
+    assert all(float(st["step"]) == 5.0 for st in oc.state_dict()["state"].values())

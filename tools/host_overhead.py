@@ -17,9 +17,23 @@ cam = R.Camera(syn.look_at_camera(64, 64, azimuth=0.7), dev, time=0.37)
 bg = torch.ones(3, device=dev); target = torch.rand(3, 64, 64, device=dev)
 params = list(pc.parameters()) + list(deform.parameters())
 
+WITH_OPT = bool(os.environ.get("HOST_OPT"))        # the optimizer-inclusive iteration (bench field with_optimizer)
+if WITH_OPT:
+    reg = importlib.import_module("4dgaussians_amd.scene.regulation"); om = importlib.import_module("4dgaussians_amd.optim")
+    opt = om.FusedAdamW([{"params": [pc._xyz], "lr": 0.00016}, {"params": list(deform.get_mlp_parameters()), "lr": 0.00016},
+                         {"params": list(deform.get_grid_parameters()), "lr": 0.0016}, {"params": [pc._features], "lr": 0.0025},
+                         {"params": [pc._opacity], "lr": 0.05}, {"params": [pc._scaling], "lr": 0.005},
+                         {"params": [pc._rotation], "lr": 0.001}], lr=0.0001, eps=1e-8)
+
+
 def step():
     image, *_ = R.render(cam, pc, deform, bg)
-    F.l1_loss(image, target).backward()
+    if WITH_OPT:
+        regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
+        (F.l1_loss(image, target) + regul).backward()
+        opt.step()
+    else:
+        F.l1_loss(image, target).backward()
     for p in params:
         p.grad = None
 
