@@ -18,8 +18,8 @@ from .pointops import knn, knn_self_i32
 
 def transpose_graph(idx: torch.Tensor, trusted: bool = False):
     """idx (..., n, k) -> (order int32 [n*k], row_start int32 [n+1]): the pairs i*k+s sorted by their target idx[i][s]
-    and where each target's pairs begin.  Built once per neighbour graph (gs4d_transpose_graph: a radix sort over the bits the targets have, shared by every
-    term of a view); it turns the backward's scatter into a gather.  trusted=True skips the range check of the indices (two
+    and where each target's pairs begin.  Built once per neighbour graph (gs4d_transpose_graph: a radix sort over the
+    bits the targets have; shared by every term of a view); it turns the backward's scatter into a gather.  trusted=True skips the range check of the indices (two
     reductions and two host synchronisations per view): for lists that come straight out of this package's knn()."""
     n, k = idx.shape[-2], idx.shape[-1]
     if n * k >= 2 ** 31:
