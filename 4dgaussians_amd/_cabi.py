@@ -41,6 +41,7 @@ def lib() -> C.CDLL:
             getattr(L, name).restype = C.c_size_t
         L.gs4d_thread_state_release.restype = None
         L.gs4d_mailbox_stats.restype = None
+        L.gs4d_forward_stats.restype = None
         atexit.register(L.gs4d_thread_state_release)       # the main thread's pinned num_rendered mailbox
         _lib = L
     return _lib
@@ -51,6 +52,13 @@ def mailbox_stats():
     fast, slow = C.c_ulonglong(0), C.c_ulonglong(0)
     lib().gs4d_mailbox_stats(C.byref(fast), C.byref(slow))
     return fast.value, slow.value
+
+
+def forward_stats():
+    """(fast, slow, regrow): mailbox_stats() plus the forwards whose speculative binning chunk had to be requested again."""
+    v = [C.c_ulonglong(0) for _ in range(3)]
+    lib().gs4d_forward_stats(*(C.byref(x) for x in v))
+    return tuple(x.value for x in v)
 
 
 def check(rc: int, what: str) -> None:
@@ -117,6 +125,47 @@ class TensorAllocator:
         if self._tensor is None:
             self._tensor = torch.empty(0, dtype=torch.uint8, device=self.device)
         return self._tensor
+
+    def close(self):
+        _live_allocators.pop(self._key, None)
+        if self.error is not None:
+            raise self.error
+
+
+def _arena_trampoline(ctx, nbytes):
+    a = _live_allocators.get(ctx)
+    if a is None:
+        return 0
+    try:
+        t = torch.empty(int(nbytes), dtype=torch.uint8, device=a.device)
+        a.tensors.append(t)
+        return t.data_ptr()
+    except Exception as ex:
+        a.error = ex
+        return 0
+
+
+_ARENA_TRAMPOLINE = ALLOC_FN(_arena_trampoline)
+
+
+class ArenaAllocator:
+    """gs4d_alloc_fn for entry points that ask for several blocks (gs4d_render_forward: activation arena, binning chunk,
+    again the binning chunk if the speculative size was short): every block is kept, in request order, in `tensors`."""
+    __slots__ = ("device", "tensors", "error", "_key")
+
+    def __init__(self, device):
+        self.device, self.tensors, self.error = device, [], None
+        self._key = _next_key[0]
+        _next_key[0] += 1
+        _live_allocators[self._key] = self
+
+    @property
+    def callback(self):
+        return _ARENA_TRAMPOLINE
+
+    @property
+    def ctx(self):
+        return C.c_void_p(self._key)
 
     def close(self):
         _live_allocators.pop(self._key, None)

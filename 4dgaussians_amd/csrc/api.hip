@@ -27,6 +27,7 @@ struct ThreadState {
     uint32_t seq = 0;
     size_t last_R = 0;
     unsigned long long fast = 0, slow = 0;      // how often the count arrived through the mailbox / the copy + sync path
+    unsigned long long regrow = 0;              // forwards whose speculative binning chunk was too small (second allocation)
 };
 thread_local ThreadState t_state;
 }  // namespace
@@ -37,6 +38,73 @@ void gs4d_set_error(const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof g_err, fmt, ap);
     va_end(ap);
+}
+
+// ---------------------------------------------------------------- GS4D_TRACE
+#include <sys/syscall.h>
+#include <unistd.h>
+namespace {
+thread_local double t_trace_last = 0.0;
+thread_local int t_trace_depth = 0;
+double trace_slow_ms()
+{
+    static const double v = [] { const char* e = getenv("GS4D_TRACE_SLOW_US"); return (e ? atof(e) : 1000.0) * 1e-3; }();
+    return v;
+}
+void trace_line(const char* fmt, ...)
+{
+    char buf[384];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[gs4d-trace %d %ld %.3f] %s\n", (int)getpid(), (long)syscall(SYS_gettid), gs4d_trace_now_ms(), buf);
+}
+}  // namespace
+
+bool gs4d_trace_on()
+{
+    static const bool v = [] { const char* e = getenv("GS4D_TRACE"); return e && e[0] && e[0] != '0'; }();
+    return v;
+}
+
+double gs4d_trace_now_ms()
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec * 1e3 + (double)t.tv_nsec * 1e-6;
+}
+
+void gs4d_trace_checkpoint(const char* what)
+{
+    const double now = gs4d_trace_now_ms();
+    if (t_trace_last > 0.0 && now - t_trace_last >= trace_slow_ms()) trace_line("SLOW %.3f ms up to: %s", now - t_trace_last, what);
+    t_trace_last = now;
+}
+
+void gs4d_trace_blocked(const char* what, double t0_ms)
+{
+    const double now = gs4d_trace_now_ms();
+    trace_line("blocked %.3f ms in %s", now - t0_ms, what);
+    t_trace_last = now;
+}
+
+Gs4dTraceScope::Gs4dTraceScope(const char* n) : name(n), t0(0.0)
+{
+    if (!gs4d_trace_on()) return;
+    t0 = gs4d_trace_now_ms();
+    t_trace_last = t0;
+    trace_line("%*senter %s", 2 * t_trace_depth, "", name);
+    t_trace_depth++;
+}
+
+Gs4dTraceScope::~Gs4dTraceScope()
+{
+    if (t0 == 0.0) return;
+    t_trace_depth--;
+    const double now = gs4d_trace_now_ms();
+    trace_line("%*sexit  %s after %.3f ms", 2 * t_trace_depth, "", name, now - t0);
+    t_trace_last = now;
 }
 
 // ---------------------------------------------------------------- per-stage timing
@@ -205,7 +273,7 @@ static int sort_passes(int W, int H)
 extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
-int gs4d_abi_version(void) { return 9; }
+int gs4d_abi_version(void) { return 10; }
 
 void gs4d_thread_state_release(void)
 {
@@ -218,6 +286,12 @@ void gs4d_mailbox_stats(unsigned long long* fast, unsigned long long* slow)
 {
     if (fast) *fast = t_state.fast;
     if (slow) *slow = t_state.slow;
+}
+
+void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsigned long long* regrow)
+{
+    gs4d_mailbox_stats(fast, slow);
+    if (regrow) *regrow = t_state.regrow;
 }
 
 void gs4d_profile_enable(int on)
@@ -275,6 +349,7 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
                            float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
                            void* stream, int* num_rendered)
 {
+    GS4D_TRACE_SCOPE("gs4d_rasterize_forward");
     hipStream_t s = (hipStream_t)stream;
     const int debug = debug_arg & 1;                // bit 1 (GS4D_FORWARD_ONLY): see include/gs4d.h
     if (num_rendered) *num_rendered = 0;
@@ -348,6 +423,7 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     if (ts.last_R) {
         guess_R = ts.last_R + ts.last_R / 8 + 4096;
         bchunk = (char*)binning_alloc(binning_ctx, BinningState::required(guess_R));
+        if (gs4d_trace_on()) gs4d_trace_checkpoint("binning allocator callback (speculative size)");
         if (!bchunk) {
             (void)hipStreamSynchronize(s);                                  // no post may arrive after this call has returned
             gs4d_set_error("binning allocator returned NULL");
@@ -357,6 +433,7 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
 
     uint32_t host_counters[2] = {0, 0};
     bool posted = false;
+    const double t_wait0 = gs4d_trace_on() ? gs4d_trace_now_ms() : 0.0;
     if (ts.mailbox) {
         static const long spin_us = [] { const char* e = getenv("GS4D_MAILBOX_SPIN_US"); long v = e ? atol(e) : 5000; return v < 0 ? 0L : v; }();
         struct timespec t0;
@@ -379,10 +456,14 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     }
     if (posted) {
         ts.fast++;
+        if (gs4d_trace_on()) gs4d_trace_blocked("num_rendered mailbox wait (host polls pinned memory, no runtime call)", t_wait0);
     } else {
         ts.slow++;
+        if (gs4d_trace_on() && ts.mailbox) gs4d_trace_blocked("num_rendered mailbox wait, TIMED OUT", t_wait0);
+        const double t_sync0 = gs4d_trace_on() ? gs4d_trace_now_ms() : 0.0;
         GS4D_HIP_CHECK(hipMemcpyAsync(host_counters, g.counters, sizeof host_counters, hipMemcpyDeviceToHost, s));
         GS4D_HIP_CHECK(hipStreamSynchronize(s));
+        if (gs4d_trace_on()) gs4d_trace_blocked("hipMemcpyAsync + hipStreamSynchronize (num_rendered fall-back)", t_sync0);
     }
     if (host_counters[1]) {
         gs4d_set_error("Point is filtered although prefiltered is set. This shouldn't happen!");
@@ -396,6 +477,7 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     if (num_rendered) *num_rendered = R;
 
     if (!bchunk || (size_t)R > guess_R) {
+        if (bchunk) ts.regrow++;
         bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R));
         if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
     }
@@ -420,6 +502,7 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
                             float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
                             void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_rasterize_backward");
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return GS4D_OK;
     if (P < 0 || R < 0 || width <= 0 || height <= 0 || !scratch_alloc || !geom_buffer || !img_buffer ||

@@ -1844,6 +1844,7 @@ int gs4d_deform_forward(const gs4d_deform_desc* d, int P, const float* points, c
                         float* out_means3D, float* out_scales, float* out_rotations, float* out_shs, char* workspace,
                         void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_deform_forward");
     hipStream_t s = (hipStream_t)stream;
     int rc = validate(d, P);
     if (rc) return rc;
@@ -1937,6 +1938,7 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
                                 const float* dL_dshs, float* dL_dpoints, float* dL_dscales_in, float* dL_drotations_in,
                                 float* dL_dshs_in, char* workspace, char* scratch, void* stream, int phases)
 {
+    GS4D_TRACE_SCOPE("gs4d_deform_backward_phases");
     hipStream_t s = (hipStream_t)stream;
     int rc = validate(d, P);
     if (rc) return rc;

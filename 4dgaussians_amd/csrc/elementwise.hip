@@ -143,6 +143,7 @@ extern "C" {
 int gs4d_activate_forward(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
                           float* scales, float* rotations_n, float* opacity, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_activate_forward");
     if (P == 0) return GS4D_OK;
     if (P < 0 || !log_scales || !rotations || !opacity_logit || !scales || !rotations_n || !opacity ||
         ((uintptr_t)rotations & 15) || ((uintptr_t)rotations_n & 15)) {
@@ -161,6 +162,7 @@ int gs4d_activate_backward(int P, const float* scales, const float* rotations, c
                            const float* g_scales, const float* g_rotations_n, const float* g_opacity,
                            float* d_log_scales, float* d_rotations, float* d_opacity_logit, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_activate_backward");
     if (P == 0) return GS4D_OK;
     if (P < 0 || !scales || !rotations || !opacity || !d_log_scales || !d_rotations || !d_opacity_logit ||
         ((uintptr_t)rotations & 15) || ((uintptr_t)g_rotations_n & 15) || ((uintptr_t)d_rotations & 15)) {
@@ -180,6 +182,7 @@ size_t gs4d_l1_loss_scratch_bytes(void) { return (size_t)L1_BLOCKS * sizeof(floa
 
 int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_l1_loss_forward");
     if (n == 0 || !a || !b || !scratch || !loss) {
         gs4d_set_error("gs4d_l1_loss_forward: empty input or null pointer");
         return GS4D_EINVAL;
@@ -198,6 +201,7 @@ int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratc
 
 int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float* g_loss, float* d_a, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_l1_loss_backward");
     if (n == 0 || !a || !b || !g_loss || !d_a) {
         gs4d_set_error("gs4d_l1_loss_backward: empty input or null pointer");
         return GS4D_EINVAL;

@@ -18,6 +18,23 @@
 
 void gs4d_set_error(const char* fmt, ...);
 
+// GS4D_TRACE=1 (environment, read once): every compute entry point logs entry / exit with wall-clock times to stderr,
+// every blocking runtime call inside the library (the num_rendered wait and its copy + synchronise fall-back, debug
+// synchronisations) logs how long it blocked, and any stretch between two launch checkpoints of one entry point that
+// exceeds GS4D_TRACE_SLOW_US (default 1000) is logged with the name of the launch it ended at -- a kernel launch that
+// takes that long is a full queue that is not draining.  One line per event: "[gs4d-trace pid tid t_ms] ...".
+bool gs4d_trace_on();
+void gs4d_trace_checkpoint(const char* what);            // time since the thread's previous checkpoint, logged if slow
+void gs4d_trace_blocked(const char* what, double t0_ms); // "blocked <ms> in <what>", always logged
+double gs4d_trace_now_ms();
+struct Gs4dTraceScope {
+    const char* name;
+    double t0;
+    explicit Gs4dTraceScope(const char* n);
+    ~Gs4dTraceScope();
+};
+#define GS4D_TRACE_SCOPE(name) Gs4dTraceScope gs4d_trace_scope_(name)
+
 #define GS4D_HIP_CHECK(expr)                                                              \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
@@ -29,6 +46,7 @@ void gs4d_set_error(const char* fmt, ...);
 
 #define GS4D_LAUNCH_CHECK(name, debug, stream)                                            \
     do {                                                                                  \
+        if (gs4d_trace_on()) gs4d_trace_checkpoint("launch " name);                       \
         hipError_t e_ = hipGetLastError();                                                \
         if (e_ == hipSuccess && (debug)) e_ = hipStreamSynchronize(stream);               \
         if (e_ != hipSuccess) {                                                           \

@@ -200,6 +200,7 @@ extern "C" {
 
 int gs4d_adamw_step(int ntensors, const gs4d_adamw_tensor* tensors, double beta1, double beta2, double eps, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_adamw_step");
     hipStream_t s = (hipStream_t)stream;
     if (ntensors < 0 || (ntensors > 0 && !tensors)) { gs4d_set_error("gs4d_adamw_step: bad tensor list"); return GS4D_EINVAL; }
     GS4D_PROF("adamw", s);
@@ -237,6 +238,7 @@ size_t gs4d_plane_reg_scratch_bytes(void) { return sizeof(float) * REG_MAX_TERMS
 
 int gs4d_plane_reg_forward(int nterms, const gs4d_plane_reg_term* terms, float* scratch, float* loss, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_plane_reg_forward");
     hipStream_t s = (hipStream_t)stream;
     RegTerms T = {};
     int rc = fill_terms(nterms, terms, T, false);
@@ -251,6 +253,7 @@ int gs4d_plane_reg_forward(int nterms, const gs4d_plane_reg_term* terms, float* 
 
 int gs4d_plane_reg_backward(int nterms, const gs4d_plane_reg_term* terms, const float* g_loss, void* stream)
 {
+    GS4D_TRACE_SCOPE("gs4d_plane_reg_backward");
     hipStream_t s = (hipStream_t)stream;
     RegTerms T = {};
     int rc = fill_terms(nterms, terms, T, true);

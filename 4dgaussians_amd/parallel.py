@@ -7,10 +7,20 @@ from __future__ import annotations
 
 import ctypes
 import os
+import sys
+import threading
+import time
 from typing import Iterable, List
 
 import torch
 import torch.distributed as dist
+
+# GS4D_TRACE=1: the same one-line-per-event log the library writes (csrc/api.hip), around the collective waits
+_TRACE = os.environ.get("GS4D_TRACE", "") not in ("", "0")
+
+
+def _trace(msg: str) -> None:
+    print(f"[gs4d-trace {os.getpid()} {threading.get_native_id()} {time.monotonic() * 1e3:.3f}] {msg}", file=sys.stderr, flush=True)
 
 
 def views_for_rank(batch: int, rank: int, world: int) -> List[int]:
@@ -220,6 +230,8 @@ class GradBucket:
     INLINE_BYTES = 2 << 20         # end-of-step regions up to this size run on the compute stream (RcclComm only)
 
     def _reduce(self, region: torch.Tensor, at_end: bool = False):
+        if _TRACE:
+            _trace(f"issue all_reduce of {region.numel() * 4} bytes ({'end of step' if at_end else 'early'})")
         if self.comm is not None:
             if at_end and region.numel() * 4 <= self.INLINE_BYTES:
                 # the small tail of the step: nothing is left to overlap with, so skip the side stream and its two
@@ -310,8 +322,13 @@ class GradBucket:
         if not self._pending:
             self._early_done = set()
             return
-        for w in self._pending:
+        for k, w in enumerate(self._pending):
+            if _TRACE:
+                t0 = time.monotonic()
+                _trace(f"enter GradBucket.finish wait {k + 1}/{len(self._pending)} ({type(w).__name__})")
             w.wait()
+            if _TRACE:
+                _trace(f"exit  GradBucket.finish wait {k + 1} after {(time.monotonic() - t0) * 1e3:.3f} ms")
         self._pending, self._early_done = [], set()
         for p, view in zip(self.live, self._grad_views):
             p.grad = view

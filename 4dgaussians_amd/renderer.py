@@ -10,6 +10,7 @@ Host-side plumbing only: all compute happens in libgs4d.so through the two drop-
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -18,6 +19,7 @@ import torch.nn as nn
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _shared_zeros
 from .fused import activate
+from .render_call import RenderCall, render_call
 
 
 class GaussianParams(nn.Module):
@@ -60,6 +62,50 @@ BATCHED_QUERY_MAX_POINTS = 2_000_000             # above this the regularised re
 MAX_FRAME = 25                                   # scene/dataset_readers.py:30: the regulariser's time step is 1 / (MAX_FRAME - 1)
 
 
+STAGED_ONLY = bool(os.environ.get("GS4D_RENDER_STAGED"))      # tests / experiments: never take the one-call path
+
+
+def _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, l1_target):
+    """The whole view through gs4d_render_forward (render_call.py) -> (image, radii, depth, loss), or None when the
+    one-call path does not apply (non-float32 / non-contiguous / CPU tensors, an empty scene, a deformation module
+    without a cached plan): the caller then takes the staged path, which also owns every error message."""
+    shs = pc._features if hasattr(pc, "_features") else pc.get_features
+    xyz, opacity, scaling, rotation = pc._xyz, pc._opacity, pc._scaling, pc._rotation
+    n = xyz.shape[0]
+    if n == 0 or shs.dim() != 3 or shs.shape[1] != 16 or not isinstance(bg_color, torch.Tensor):
+        return None
+    net, time, force = None, None, None
+    if "coarse" not in stage and deform is not None:
+        net = getattr(deform, "deformation_net", deform)
+        if not hasattr(net, "cached_plan") or not hasattr(cam, "time_force_columns"):
+            return None
+        time, force = cam.time_force_columns(n, xyz.device)
+    try:
+        call = RenderCall(cam, bg_color, scaling_modifier, pc.active_sh_degree, False, net, time, force, l1_target,
+                          shs_grad_hook)
+    except NotImplementedError:
+        return None                       # unsupported deformation configuration: the staged path raises it
+    if not call.applicable((xyz, scaling, rotation, opacity, shs)):
+        return None
+    return render_call(call, xyz, scaling, rotation, opacity, shs, screenspace_points)
+
+
+def render_with_l1(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
+                   target: torch.Tensor, scaling_modifier: float = 1.0, stage: str = "fine", shs_grad_hook=None):
+    """render() followed by l1_loss(image, target) (train.py:203, utils/loss_utils.py:20-21) with the loss computed
+    inside the same library call -> (loss, image, screenspace_points, visibility_filter, radii, depth)."""
+    if not STAGED_ONLY and torch.is_grad_enabled():
+        screenspace_points = _shared_zeros(tuple(pc._xyz.shape), pc._xyz.device).detach().requires_grad_(True)
+        out = _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, target)
+        if out is not None:
+            image, radii, depth, loss = out
+            return loss, image, screenspace_points, radii > 0, radii, depth
+    from .fused import l1_loss
+    image, screenspace_points, vis, radii, depth = render(cam, pc, deform, bg_color, scaling_modifier, stage,
+                                                          shs_grad_hook=shs_grad_hook)
+    return l1_loss(image, target), image, screenspace_points, vis, radii, depth
+
+
 def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
            scaling_modifier: float = 1.0, stage: str = "fine", debug: bool = False, shs_grad_hook=None,
            regularise: bool = False, max_frame: int = MAX_FRAME, _image_only: bool = False):
@@ -76,6 +122,12 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
         screenspace_points = _shared_zeros(tuple(pc._xyz.shape), pc._xyz.device).detach().requires_grad_(True)
     else:                                   # never read without a backward pass: no fill kernel for it
         screenspace_points = torch.empty_like(pc._xyz)
+    if not (regularise or debug or STAGED_ONLY):
+        # the common case in one library call per direction (render_call.py); same kernels, same results
+        out = _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, None)
+        if out is not None:
+            image, radii, depth, _ = out
+            return image if _image_only else (image, screenspace_points, radii > 0, radii, depth)
     settings = GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,

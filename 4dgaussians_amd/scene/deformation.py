@@ -53,6 +53,7 @@ class HexOrderCache:
         import os
         self.refresh = int(os.environ.get("GS4D_HEX_ORDER_REFRESH", "16"))
         self.entries = {}
+        self.records = self.reuses = 0          # backward passes that ranked the points / walked a cached order
 
     def clear(self):
         self.entries.clear()
@@ -67,9 +68,16 @@ class HexOrderCache:
         if e is None:
             if len(self.entries) >= 4:
                 self.entries.clear()
-            e = self.entries[key] = [torch.empty(L * 3 * P, dtype=torch.int32, device=dev), self.refresh]
+            # starts as the identity order of every (level, sort plane): should the recording backward fail half way
+            # (an exception between its phases), what a later pass walks is still a permutation of the points -- the
+            # order decides only how well adds are combined, a non-permutation would drop or double gradients
+            e = self.entries[key] = [torch.arange(P, dtype=torch.int32, device=dev).repeat(L * 3), self.refresh]
         valid = e[1] < self.refresh
         e[1] = e[1] + 1 if valid else 1
+        if valid:
+            self.reuses += 1
+        else:
+            self.records += 1
         g.hex_order, g.hex_order_valid = e[0].data_ptr(), int(valid)
 
 
@@ -396,9 +404,9 @@ class Deformation(nn.Module):
         self.__dict__.pop("_hex_order_cache", None)
         return super()._apply(fn, *a, **k)
 
-    def forward_dynamic(self, points, scales, rotations, opacity, shs, time, force, prev_frames=None):
-        if prev_frames is not None:
-            raise NotImplementedError("prev_frames conditioning is outside the hot path (SURVEY.md section 8)")
+    def cached_plan(self):
+        """-> (params, cfg): the parameter list in the order the C ABI consumes it and the per-parameter-set plan
+        (cfg["plan"]: filled gs4d_deform_desc, gradient layout), rebuilt only when a parameter changed storage."""
         cache = self.__dict__.get("_step_cache")
         # The cached plan is valid while (a) every cached parameter keeps its storage, (b) the aabb Parameter is still
         # the cached object (HexPlaneField.set_aabb installs a new one) and (c) the switches read from `args` are
@@ -415,6 +423,12 @@ class Deformation(nn.Module):
         if oc is None:
             oc = self.__dict__["_hex_order_cache"] = HexOrderCache()
         cfg["hex_order_cache"] = oc
+        return params, cfg
+
+    def forward_dynamic(self, points, scales, rotations, opacity, shs, time, force, prev_frames=None):
+        if prev_frames is not None:
+            raise NotImplementedError("prev_frames conditioning is outside the hot path (SURVEY.md section 8)")
+        params, cfg = self.cached_plan()
         out = _DeformFunction.apply(points, scales, rotations, shs, time, force, cfg, *params)
         # opacity passes through (no_do): the reference's opacity[:, :1] is the tensor itself when it is (P, 1)
         return out[0], out[1], out[2], opacity if opacity.shape[1] == 1 else opacity[:, :1], out[3]

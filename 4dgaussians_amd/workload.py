@@ -65,6 +65,22 @@ def calibrate_log_scale_offset(pc, deform, cam, cam_np, bg, target_tiles: float 
     return offset
 
 
+def build_views(name: str, dev, rank: int = 0, n: int = 8):
+    """The n distinct (camera, timestamp, target image) views rank `rank` cycles through, one per training step, as
+    train.py:168-189 draws a random view per iteration.  View 0 is build_scene's view (the one the parity tests and the
+    CPU baseline use); the others move the camera around and above the scene and draw their own timestamp / target."""
+    cfg = syn.CONFIGS[name]
+    W, H = cfg["W"], cfg["H"]
+    rng = np.random.default_rng(1234 + rank)
+    views = []
+    for j in range(n):
+        cam_np = syn.look_at_camera(W, H, azimuth=0.7 + 0.6 * rank + 0.785 * j, elevation=0.35 + 0.12 * ((j * 3) % 5 - 2) * (j > 0))
+        cam = Camera(cam_np, dev, time=float(rng.uniform(0, 1)), force=0.0)
+        target = torch.rand(3, H, W, device=dev, generator=torch.Generator(device=dev).manual_seed(99 + rank + 1000 * j))
+        views.append(types.SimpleNamespace(cam=cam, cam_np=cam_np, target=target))
+    return views
+
+
 def build_scene(name: str, dev, P: int | None = None, rank: int = 0, calibrate: bool = True):
     """-> dict(pc, deform, cam, cam_np, raw, bg, target, log_s0_offset, W, H, P) for a BASELINE.json config: what
     bench.py's rank `rank` renders each step (its own azimuth / timestamp / target image)."""

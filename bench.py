@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C2")
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (then the line is not the headline config)")
+    ap.add_argument("--views", type=int, default=8,
+                    help="distinct (camera, timestamp, target) views each rank cycles through, one per step (train.py:168-189 draws a random view per iteration)")
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-pass", action="store_true", help="skip the separate optimizer-inclusive timing loop")
@@ -122,6 +124,16 @@ def main():
     scene = Wl.build_scene(args.config, dev, P=args.P, rank=rank, calibrate=False)
     pc, deform, cam, cam_np, bg, target = (scene[k] for k in ("pc", "deform", "cam", "cam_np", "bg", "target"))
     P, W, H = scene["P"], scene["W"], scene["H"]
+    # the views this rank cycles through (view 0 = the scene's own view: calibration, parity tests, CPU baseline)
+    views = Wl.build_views(args.config, dev, rank=rank, n=max(1, args.views))
+    V = len(views)
+    step_no = [0]
+
+    def next_view():
+        v = views[step_no[0] % V]
+        step_no[0] += 1
+        return v
+
     if dp:  # replicas start identical
         par.GradBucket.exchange_in_world_of_one = rehearse
         for p in list(pc.parameters()) + list(deform.parameters()):
@@ -178,8 +190,9 @@ def main():
         deform.deformation_net.data_grad_hook = data_hook
 
     def train_step():
-        image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
-        loss = F.l1_loss(image, target)
+        v = next_view()
+        # render + L1 in one library call per direction (renderer.render_with_l1 -> gs4d_render_forward / _backward)
+        loss, *_ = R.render_with_l1(v.cam, pc, deform, bg, v.target, shs_grad_hook=hook)
         if dp:
             loss = loss / world                           # SUM over ranks == mean over the global batch
         loss.backward()
@@ -189,7 +202,7 @@ def main():
             p.grad = None
 
     def fps_step():
-        R.render_for_image(cam, pc, deform, bg)
+        R.render_for_image(next_view().cam, pc, deform, bg)
 
     step = train_step if args.mode == "train" else fps_step
 
@@ -215,12 +228,16 @@ def main():
     L.gs4d_profile_reset()
     L.gs4d_profile_select(None if args.no_stage_events else dominant.encode())
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
+    stats0 = cabi.forward_stats()
+    step_no[0] = 0                          # the timed region renders views 0, 1, ..., steps - 1 (mod V)
     t0 = time.perf_counter()
     for i in range(args.steps):
         step()
     t_issued = time.perf_counter() - t0
     sync()
     dt = time.perf_counter() - t0
+    stats1 = cabi.forward_stats()
+    view_weight = [sum(1 for i in range(args.steps) if i % V == j) / args.steps for j in range(V)]
     _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step")
     _dbg(f"timed region done: {dt / args.steps * 1e3:.3f} ms per step")
     L.gs4d_profile_enable(0)
@@ -237,6 +254,10 @@ def main():
             if calls.value:
                 out[s] = ms.value / calls.value
         return out
+
+    def hex_order_counts():
+        oc = deform.deformation_net.__dict__.get("_hex_order_cache")
+        return None if oc is None else {"ranked": oc.records, "reused": oc.reuses, "note": "whole run, not only the timed region"}
 
     timed = read_stages()                   # the dominant stage, HIP events inside the timed region
     stages = dict(timed)
@@ -263,6 +284,7 @@ def main():
         L.gs4d_profile_select(None if args.no_stage_events else b"blend_forward")
         L.gs4d_profile_enable(0 if args.no_stage_events else 1)
         fps_frames = max(100, 5 * args.steps)
+        step_no[0] = 0
         t0 = time.perf_counter()
         for _ in range(fps_frames):
             fps_step()
@@ -276,63 +298,137 @@ def main():
             fps_dt = float(t.item())
 
     if rank == 0:
-        # workload statistics for the roofline numerators (one extra untimed forward through the C-level API)
-        with torch.no_grad():
-            Rn, _, _, radii, gb, bb, ib = rasterize_untimed()
-            view = Craw.state_view(P, Rn, W, H, gb, bb, ib)
-            nc = view["n_contrib"].to(torch.int64)
-            gy, gx = (H + 15) // 16, (W + 15) // 16
-            pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=dev)
-            pad[:H, :W] = nc
-            tile_max = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
-            pairs_bwd = int(tile_max.sum().item()) * 256        # (pixel, Gaussian) pairs the backward evaluates
+        # workload statistics for the roofline numerators: one extra untimed forward per view through the C-level API,
+        # averaged with the weight each view had in the timed region
+        def view_stats(v):
+            with torch.no_grad():
+                Rv, _, _, radii, gb, bb, ib = Wl.rasterize_untimed(pc, deform, v.cam, v.cam_np, bg)
+                view = Craw.state_view(P, Rv, W, H, gb, bb, ib)
+                nc = view["n_contrib"].to(torch.int64)
+                gy, gx = (H + 15) // 16, (W + 15) // 16
+                pad = torch.zeros(gy * 16, gx * 16, dtype=torch.int64, device=dev)
+                pad[:H, :W] = nc
+                tile_max = pad.view(gy, 16, gx, 16).amax(dim=(1, 3))
+                return Rv, int(tile_max.sum().item()) * 256     # instances; (pixel, Gaussian) pairs the blends evaluate
+        per_view = [view_stats(v) for v in views]
+        Rn = sum(w * r for w, (r, _) in zip(view_weight, per_view))
+        pairs_bwd = sum(w * p for w, (_, p) in zip(view_weight, per_view))
+        fps_weight = [sum(1 for i in range(fps_frames) if i % V == j) / max(fps_frames, 1) for j in range(V)]
+        Rn_fps = sum(w * r for w, (r, _) in zip(fps_weight, per_view))
+        pairs_fps = sum(w * p for w, (_, p) in zip(fps_weight, per_view))
+
+        def pmc_file(kind):
+            """This round's committed rocprofv3 PMC summary (profiles/r03_pmc_<kind>.json, written by
+            tools/profile_round.sh from separate counter passes over this same command), else last round's."""
+            for r in ("r03", "r02"):
+                path = os.path.join(ROOT, "profiles", f"{r}_pmc_{kind}.json")
+                if os.path.exists(path):
+                    return path
+            return None
+
         def pmc_traffic(kernel_prefix):
-            """(HBM bytes per launch, source file) of a kernel from this round's committed rocprofv3 PMC passes
-            (profiles/r02_pmc_traffic.json, written by tools/profile_round.sh from separate FETCH_SIZE / WRITE_SIZE
-            runs of this same command), or (None, None) for another workload or when the file is absent."""
-            path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+            """(HBM bytes per launch, source file) of a kernel from the FETCH_SIZE / WRITE_SIZE passes, or (None, None)
+            for another workload or when the file is absent."""
+            path = pmc_file("traffic")
             try:
                 d = json.load(open(path))
                 for k, v in d["kernels"].items():
                     if k.startswith(kernel_prefix) and args.config == "C2" and args.P is None:
                         return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0, os.path.relpath(path, ROOT)
-            except (OSError, KeyError, ValueError):
+            except (OSError, KeyError, ValueError, TypeError):
                 pass
             return None, None
 
-        def blend_roofline(kernel, stage_ms, alg_bytes, flop_per_pair):
+        def pmc_lds(kernel_prefix, stage_ms):
+            """LDS traffic of a kernel from the SQ_INSTS_LDS pass: wave-level LDS instructions per launch x 64 lanes x the
+            bytes per lane the kernel's source uses (tools/pmc_lds.py records both), over this run's launch duration,
+            against the ~150 TB/s aggregate LDS peak (MI355X_MICROARCH.md)."""
+            path = pmc_file("lds")
+            try:
+                d = json.load(open(path))
+                for k, v in d["kernels"].items():
+                    if k.startswith(kernel_prefix) and args.config == "C2" and args.P is None:
+                        gb = v["lds_bytes_per_launch"] / (stage_ms * 1e-3) / 1e9
+                        return {"lds_GBps": round(gb, 1), "lds_peak_GBps": 150000.0, "lds_frac": round(gb / 150000.0, 4),
+                                "lds_insts_per_launch": v["SQ_INSTS_LDS"], "bytes_per_lane_assumed": v["bytes_per_lane"],
+                                "bank_conflict_cycles_per_active_lds_cycle": v.get("conflict_ratio"),
+                                "source": os.path.relpath(path, ROOT)}
+            except (OSError, KeyError, ValueError, TypeError):
+                pass
+            return None
+
+        def blend_roofline(kernel, stage_ms, alg_bytes, flop_per_pair, pairs):
             """Both blend kernels are bound by fp32 VALU issue (PMC: VALU busy ~76 %, MFMA pipe idle,
             HBM at a few per cent), so `bound` / `frac` are quoted against the fp32 vector peak with SURVEY 8(d)'s
             per-pair flop figure; the HBM view of the same launch is kept beside it."""
             sec = stage_ms * 1e-3
-            tf = pairs_bwd * flop_per_pair / sec / 1e12
+            tf = pairs * flop_per_pair / sec / 1e12
             traffic, src = pmc_traffic(kernel)
             return {"kernel": kernel.split("<")[0], "bound": "valu", "achieved": round(tf, 3), "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(tf / FP32_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
-                    "avg_launch_ms": round(stage_ms, 4), "pairs": pairs_bwd, "flop_per_pair": flop_per_pair,
+                    "avg_launch_ms": round(stage_ms, 4), "pairs": int(pairs), "flop_per_pair": flop_per_pair,
                     "hbm": {"algorithmic_bytes": alg_bytes, "achieved_GBps": round(alg_bytes / sec / 1e9, 2),
                             "peak_GBps": HBM_PEAK_GBS, "frac": round(alg_bytes / sec / 1e9 / HBM_PEAK_GBS, 5)},
-                    "note": "pairs = sum over tiles of 256 x (list entries up to the tile's last contributor); "
-                            "flop_per_pair from SURVEY.md 8(d); peak = fp32 vector / f32-MFMA 157.3 TFLOP/s"}
+                    "lds": pmc_lds(kernel, stage_ms),
+                    "note": "pairs = sum over tiles of 256 x (list entries up to the tile's last contributor), mean over the "
+                            "views of the timed region; flop_per_pair from SURVEY.md 8(d); peak = fp32 vector / f32-MFMA 157.3 TFLOP/s"}
 
         roofline = None
         if args.mode == "train" and "blend_backward" in stages:
             # SURVEY.md 8(d): 44 B/instance staged + 40 B/instance gradient rows + 24 B/pixel (dL/dcolor 12, dL/ddepth 4, final_T 4, n_contrib 4)
-            roofline = blend_roofline("blend_backward_kernel", stages["blend_backward"], 84.0 * Rn + 24.0 * W * H, 60)
+            roofline = blend_roofline("blend_backward_kernel", stages["blend_backward"], 84.0 * Rn + 24.0 * W * H, 60, pairs_bwd)
         elif "blend_forward" in stages:
-            roofline = blend_roofline("blend_forward_kernel<false, false>", stages["blend_forward"], 44.0 * Rn + 24.0 * W * H, 25)
+            roofline = blend_roofline("blend_forward_kernel<false, false>", stages["blend_forward"], 44.0 * Rn + 24.0 * W * H, 25, pairs_bwd)
+
+        # one roofline entry per stage that takes >= 5 % of the step (SURVEY.md 8(d)'s algorithmic figures x the units of
+        # one launch / the stage's device time / the peak that bounds it)
+        net = deform.deformation_net
+        lin = [m for seq in (net.feature_out2, net.pos_deform, net.scales_deform, net.rotations_deform, net.shs_deform)
+               for m in seq if isinstance(m, torch.nn.Linear)]
+        mlp_flops = 2.0 * sum(m.in_features * m.out_features for m in lin)          # per Gaussian, forward
+        kc = net.args.kplanes_config
+        Lv, Cp = len(net.args.multires), int(kc["output_coordinate_dim"])
+        gather_bytes = Lv * 6 * 4 * Cp * 4.0 + Lv * Cp * 4.0                         # corner rows gathered + features written
+        L2_PEAK_GBS = 34500.0                                                        # MI355X_MICROARCH.md: aggregate L2
+        spec = {  # stage -> (bound, units of work per launch, unit, peak, kernel name prefix in the PMC files, what)
+            "hexplane_forward": ("l2-gather", P * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_forward_kernel",
+                                 "levels*6*4*C*4 B gathered + L*C*4 B written per Gaussian (SURVEY upper bound: served by L2 / Infinity Cache, the planes themselves are read from HBM once)"),
+            "mlp_forward": ("mfma", P * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_forward_kernel", "2*sum(in*out) FLOP per Gaussian, exact-f32 MFMA"),
+            "preprocess": ("hbm", 311.0 * P, "GB/s", HBM_PEAK_GBS, "preprocess_kernel", "311 B per Gaussian"),
+            "radix_sort": ("hbm", 144.0 * Rn, "GB/s", HBM_PEAK_GBS, "segment_depth_sort_kernel", "24 B per instance and pass x 6 LSD passes (the tile-first sort moves 72 B per instance)"),
+            "blend_forward": ("valu", 25.0 * pairs_bwd, "TFLOP/s", FP32_PEAK_TFLOPS, "blend_forward_kernel<false, true>", "25 FLOP per (pixel, Gaussian) pair"),
+            "blend_backward": ("valu", 60.0 * pairs_bwd, "TFLOP/s", FP32_PEAK_TFLOPS, "blend_backward_kernel", "60 FLOP per (pixel, Gaussian) pair"),
+            "geom_backward": ("hbm", 567.0 * P + 48.0 * Rn, "GB/s", HBM_PEAK_GBS, "geom_backward_kernel", "567 B per Gaussian + 48 B per instance row"),
+            "mlp_backward": ("mfma", P * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_backward_kernel", "input gradients of every Linear: the forward's FLOP count"),
+            "weight_grads": ("mfma", P * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "dw_partial_kernel", "weight gradients of every Linear: the forward's FLOP count"),
+            "hexplane_backward": ("l2-gather", 2.0 * P * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_backward_point_kernel", "twice the forward's gather figure (read the corners, add the gradients)"),
+        }
+        step_ms = sum(stages.values()) or 1.0
+        rooflines = []
+        for st, (bound, work, unit, peak, kern, what) in spec.items():
+            ms = stages.get(st)
+            if not ms or ms < 0.05 * step_ms:
+                continue
+            ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
+            traffic, src = pmc_traffic(kern)
+            e = {"stage": st, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+                 "stage_ms": round(ms, 4), "share_of_step": round(ms / step_ms, 3), "work_per_launch": work, "what": what,
+                 "dominant_kernel": kern.split("<")[0], "dominant_kernel_traffic": traffic, "traffic_source": src}
+            if st in ("radix_sort", "blend_forward", "blend_backward"):
+                e["lds"] = pmc_lds(kern, ms)
+            rooflines.append(e)
 
         render_fps = None
         if fps_dt is not None:
             render_fps = {"metric": "render FPS", "value": round(world * fps_frames / fps_dt, 2), "unit": "frames/s",
                           "ms_per_frame": round(fps_dt / fps_frames * 1e3, 4), "frames": fps_frames, "n_gpus": world,
-                          "what": f"render_for_image (deformation forward + rasterizer forward, no grad) of the same scene at {W}x{H}",
+                          "what": f"render_for_image (deformation forward + rasterizer forward, no grad) of the same scene at {W}x{H}, {V} views cycled",
                           # the forward-only instantiation (no segment checkpoints for a backward)
-                          "roofline": blend_roofline("blend_forward_kernel<false, false>", fps_blend_ms, 44.0 * Rn + 24.0 * W * H, 25) if fps_blend_ms else None}
+                          "roofline": blend_roofline("blend_forward_kernel<false, false>", fps_blend_ms, 44.0 * Rn_fps + 24.0 * W * H, 25, pairs_fps) if fps_blend_ms else None}
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args, raw, cam_np, cam.time, deform, target.cpu().numpy())
+            cpu = cpu_baseline(args, raw, cam_np, cam.time, deform, target.cpu().numpy())      # view 0
 
         unit = "view-iterations/s (fwd+bwd)" if args.mode == "train" else "frames/s"
         metric = "train iters/sec (fwd+bwd)" if args.mode == "train" else "render FPS"
@@ -342,13 +438,20 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, P={P} Gaussians, SH degree 3, "
                                    f"{'mutant' if args.config != 'C5' else 'force_blend'}-shaped HexPlane deformation, "
-                                   f"1 view per GPU per step", "global_batch_views": world,
-                       "parallelism": f"view-dp{world}", "num_rendered": Rn, "tiles_per_gaussian": round(Rn / P, 3),
+                                   f"1 view per GPU per step, {V} distinct (camera, timestamp, target) views cycled",
+                       "global_batch_views": world, "views_cycled": V,
+                       "parallelism": f"view-dp{world}", "num_rendered": round(Rn, 1), "tiles_per_gaussian": round(Rn / P, 3),
+                       "num_rendered_per_view": [r for r, _ in per_view],
                        "log_s0_offset": round(log_s0_offset, 4),
                        "grad_allreduce_bytes": bucket.nbytes, "collectives": collectives if dp else None,
                        "collectives_fallback": collectives_fallback,
-                       "num_rendered_wait": dict(zip(("mailbox", "copy_sync_fallback"), cabi.mailbox_stats()))},
-            "roofline": roofline, "cpu_baseline": cpu, "render_fps": render_fps,
+                       "num_rendered_wait": dict(zip(("mailbox", "copy_sync_fallback"), cabi.mailbox_stats())),
+                       # the timed region only: waits that fell back to copy + sync, forwards whose speculative binning
+                       # chunk (previous view's R + 1/8) was too small, plane-gradient point orders ranked / reused
+                       "timed_region": {"copy_sync_fallback": stats1[1] - stats0[1], "binning_second_allocations": stats1[2] - stats0[2],
+                                        "hex_order": hex_order_counts()},
+                       "render_path": "staged" if R.STAGED_ONLY else "gs4d_render_forward / gs4d_render_backward (one call per direction)"},
+            "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu, "render_fps": render_fps,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",
         }
@@ -368,6 +471,8 @@ def main():
             {"params": [pc._rotation], "lr": 0.001, "name": "rotation"}], lr=0.0001, eps=1e-8)
 
         def opt_step():
+            v = next_view()
+            cam, target = v.cam, v.target
             image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
             regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
             if not dp:
@@ -404,6 +509,8 @@ def main():
     full_stage = None
     if args.mode == "train" and not args.no_optimizer_pass:
         def full_step():
+            v = next_view()
+            cam, target = v.cam, v.target
             image, _, _, _, _, rd, _ = R.render(cam, pc, deform, bg, shs_grad_hook=hook, regularise=True)
             regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
             knn_terms = (0.000001 * rd["momentum"] + rd["knn_xyz"] + 0.1 * rd["knn_long"] + rd["knn_rot"]

@@ -145,6 +145,9 @@ int gs4d_rasterize_backward(
  */
 void gs4d_thread_state_release(void);
 void gs4d_mailbox_stats(unsigned long long* fast, unsigned long long* slow);
+/* The same two counters plus *regrow: forwards of the calling thread whose speculative binning chunk (previous
+ * num_rendered + 1/8) turned out too small, i.e. that called binning_alloc a second time. */
+void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsigned long long* regrow);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; rasterizer_impl.cu:54-66,141-153. `present` is device uint8/bool [P]. */
 int gs4d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -345,6 +348,85 @@ int gs4d_activate_backward(int P, const float* scales, const float* rotations, c
 size_t gs4d_l1_loss_scratch_bytes(void);
 int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream);
 int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float* g_loss, float* d_a, void* stream);
+
+/* ---- the whole hot path of one view in one call per direction ----
+ * No single counterpart in the reference, which composes these stages in Python: gaussian_renderer/renderer.py:123-147
+ * (deformation query, then scales = exp, rotations = normalize, opacity = sigmoid), :207-216 (rasterizer call) and
+ * train.py:203 / utils/loss_utils.py:20-21 (L1 loss).  gs4d_render_forward = gs4d_deform_forward ->
+ * gs4d_activate_forward -> gs4d_rasterize_forward [-> gs4d_l1_loss_forward]; gs4d_render_backward = the reverse chain.
+ * Nothing else runs on the device, so the results are bit-identical to calling the stages one by one; what goes away
+ * is the host time between them (one call, three allocator callbacks per direction instead of ~30 tensor
+ * allocations and four framework-level autograd nodes).  Requirements: P > 0, SH colours (no colors_precomp /
+ * cov3D_precomp), M == 16 when a deformation field is given; other cases use the per-stage entry points. */
+typedef struct gs4d_render_desc {
+    int P, D, M;                  /* Gaussians, active SH degree, SH coefficients per Gaussian */
+    int width, height;
+    float scale_modifier, tan_fovx, tan_fovy;
+    int prefiltered;
+    int flags;                    /* as gs4d_rasterize_forward's `debug`: bit 0 debug, GS4D_FORWARD_ONLY */
+    const float* background;      /* device [3] */
+    const float* viewmatrix;      /* device [16] */
+    const float* projmatrix;      /* device [16] */
+    const float* cam_pos;         /* device [3] */
+    const float* xyz;             /* device [P,3] */
+    const float* log_scales;      /* device [P,3], pre-activation */
+    const float* rotations;       /* device [P,4], pre-activation, 16-byte aligned */
+    const float* opacity_logit;   /* device [P] */
+    const float* shs;             /* device [P,M,3], 16-byte aligned */
+    const gs4d_deform_desc* deform;   /* NULL: coarse stage (renderer.py:123-125), the raw parameters are activated and rendered */
+    const float* time;            /* device [P]; read only when deform != NULL */
+    const float* force;           /* device [P] */
+    const float* target;          /* device [3,H,W] (16-byte aligned) or NULL.  With a target the forward also writes
+                                     loss[0] = mean |color - target| and the backward may start from g_loss. */
+} gs4d_render_desc;
+
+/* Filled by the forward, handed back to the backward unchanged.  `arena` (activations, geometry and image chunks) is
+ * the first block the forward's allocator returned, `binning` the last one (the binning chunk; the allocator is asked
+ * a second time for it only when the speculative size was too small): the caller keeps both alive until the backward
+ * has been issued. */
+typedef struct gs4d_render_state {
+    char* arena;
+    size_t arena_bytes;
+    char* binning;
+    size_t binning_bytes;
+    int num_rendered;
+    int reserved_;
+} gs4d_render_state;
+
+/* out_color [3,H,W], out_depth [1,H,W], radii [P]: written in full.  loss: device [1], required with a target. */
+int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* alloc_ctx,
+                        float* out_color, float* out_depth, int* radii, float* loss,
+                        gs4d_render_state* state, void* stream);
+
+/* Gradient destinations of the backward, all written in full (none needs clearing by the caller) except `deform`,
+ * whose arrays follow gs4d_deform_backward's rule (zero-initialised by the caller, accumulated into). */
+typedef struct gs4d_render_grads {
+    float* dL_dmeans2D;           /* [P,3] screen-space gradient (the densifier's statistic) */
+    float* d_xyz;                 /* [P,3] */
+    float* d_log_scales;          /* [P,3] */
+    float* d_rotations;           /* [P,4], 16-byte aligned */
+    float* d_opacity_logit;       /* [P] */
+    float* d_shs;                 /* [P,M,3], 16-byte aligned */
+    const gs4d_deform_grads* deform;   /* required when the descriptor has a deformation field */
+} gs4d_render_grads;
+
+/* Optional progress callback of the backward, called on the calling thread between launches: data-parallel callers
+ * start exchanging gradients that are already final while the rest of the backward is still being issued.
+ *   GS4D_RENDER_STAGE_RASTER_DONE  d_shs and dL_dmeans2D are final (all launches that write them are in the stream)
+ *   GS4D_RENDER_STAGE_DATA_DONE    d_xyz, d_log_scales, d_rotations, d_opacity_logit and the plane / force_time_embed
+ *                                  gradients are final; only the Linear weight gradients follow */
+#define GS4D_RENDER_STAGE_RASTER_DONE 1
+#define GS4D_RENDER_STAGE_DATA_DONE 2
+typedef void (*gs4d_render_stage_fn)(void* ctx, int stage);
+
+/* Exactly one of dL_dcolor [3,H,W] and g_loss (device [1], the gradient of the forward's loss; needs the descriptor's
+ * target and the forward's out_color) is non-NULL; dL_ddepth [1,H,W] may be NULL (zero).  radii: the forward's.
+ * alloc is called once, for the backward's scratch (free again when the stream has run the call). */
+int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* state,
+                         const float* out_color, const int* radii,
+                         const float* dL_dcolor, const float* dL_ddepth, const float* g_loss,
+                         gs4d_alloc_fn alloc, void* alloc_ctx, const gs4d_render_grads* grads,
+                         gs4d_render_stage_fn stage_fn, void* stage_ctx, void* stream);
 
 /* ---- optimizer step and grid regularisers (the per-iteration work right after the render path;
  * SURVEY.md section 8(f) rank 2) ----

@@ -62,7 +62,8 @@ def test_c2_composed_step_matches_oracle_composition():
         DR.forward_dynamic(sd, cfg, t("xyz"), t("log_scales"), t("rot"), t("opacity_logit"), t("sh"),
                            torch.full((scene["P"], 1), cam.time), torch.zeros(scene["P"], 1), cap)
     keep = (cap["relu_margin"] >= 1e-5).numpy()
-    assert keep.mean() > 0.9, keep.mean()
+    print(f"C2 composed step: Gaussians dropped for a ReLU input within 1e-5 of zero: {1 - keep.mean():.4%}")
+    assert 1 - keep.mean() <= 0.05, f"{1 - keep.mean():.3%} of the Gaussians dropped (bar: 5 %)"
     raw = {k: np.ascontiguousarray(v[keep]) for k, v in raw.items()}
     P = int(keep.sum())
     pc = R.GaussianParams(raw, dev)
@@ -88,10 +89,16 @@ def test_c2_composed_step_matches_oracle_composition():
             x.retain_grad()
         return out
 
+    # The stage boundaries exist as Python-visible tensors only on the STAGED path (three autograd nodes over the
+    # per-stage entry points); render()'s default one-call path (gs4d_render_forward) launches the same kernels in the
+    # same order and is held bit for bit to the staged path on this same scene by tests/test_gpu_render_call.py.
+    staged_before = R.STAGED_ONLY
+    R.STAGED_ONLY = True
     R.activate, deform.forward_dynamic = capturing_activate, capturing_forward_dynamic
     try:
         image, ssp, vis, radii, depth = R.render(cam, pc, deform, scene["bg"])
     finally:
+        R.STAGED_ONLY = staged_before
         R.activate = orig_activate
         del deform.forward_dynamic
     sc_a, rot_a, op_a = captured["act"]
