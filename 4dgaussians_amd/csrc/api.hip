@@ -32,6 +32,10 @@ struct ThreadState {
 thread_local ThreadState t_state;
 }  // namespace
 
+#include <atomic>
+static std::atomic<unsigned long long> g_alloc_calls{0};
+void gs4d_note_alloc() { g_alloc_calls.fetch_add(1, std::memory_order_relaxed); }
+
 void gs4d_set_error(const char* fmt, ...)
 {
     va_list ap;
@@ -207,7 +211,7 @@ size_t ImageState::required(size_t npix, size_t ntiles)
     return (size_t)p + 256;
 }
 
-BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes)
+BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes, bool checkpoints)
 {
     BinningState b;
     gs4d_obtain(chunk, b.keys_unsorted, R);
@@ -217,17 +221,23 @@ BinningState BinningState::from_chunk(char*& chunk, size_t R, int passes)
     gs4d_obtain(chunk, b.values_tmp[0], R);
     gs4d_obtain(chunk, b.values_tmp[1], R);
     gs4d_obtain(chunk, b.hist, (size_t)256 * gs4d_sort_blocks(R) + 256);
+    // the blend's segment checkpoints (80 of the ~116 bytes per instance) come last and exist only when a backward
+    // may follow: a GS4D_FORWARD_ONLY frame (render FPS, evaluation) neither writes nor reserves them
     b.seg_slots = R / GS4D_SEG_SLOT_DIV + 2;
-    gs4d_obtain(chunk, b.seg_owner, b.seg_slots);
-    gs4d_obtain(chunk, b.ckpt, b.seg_slots * GS4D_CKPT_FIELDS * 128);
+    b.seg_owner = nullptr;
+    b.ckpt = nullptr;
+    if (checkpoints) {
+        gs4d_obtain(chunk, b.seg_owner, b.seg_slots);
+        gs4d_obtain(chunk, b.ckpt, b.seg_slots * GS4D_CKPT_FIELDS * 128);
+    }
     b.sorted = passes > 0 ? (passes - 1) & 1 : 0;
     return b;
 }
 
-size_t BinningState::required(size_t R)
+size_t BinningState::required(size_t R, bool checkpoints)
 {
     char* p = nullptr;
-    BinningState::from_chunk(p, R, 1);
+    BinningState::from_chunk(p, R, 1, checkpoints);
     return (size_t)p + 256;
 }
 
@@ -273,6 +283,7 @@ static int sort_passes(int W, int H)
 extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
+unsigned long long gs4d_debug_alloc_calls(void) { return g_alloc_calls.load(std::memory_order_relaxed); }
 int gs4d_abi_version(void) { return 10; }
 
 void gs4d_thread_state_release(void)
@@ -330,6 +341,7 @@ int gs4d_profile_read(const char* stage, double* total_ms, long* calls)
 
 size_t gs4d_geometry_bytes(int P) { return GeomState::required((size_t)P); }
 size_t gs4d_binning_bytes(int R) { return BinningState::required((size_t)R); }
+size_t gs4d_binning_bytes_forward_only(int R) { return BinningState::required((size_t)R, false); }
 size_t gs4d_image_bytes(int width, int height)
 {
     const size_t gx = (width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
@@ -380,11 +392,13 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
         return GS4D_EINVAL;
     }
 
+    gs4d_note_alloc();
     char* chunk = (char*)geom_alloc(geom_ctx, GeomState::required((size_t)P));
     if (!chunk) { gs4d_set_error("geometry allocator returned NULL"); return GS4D_EALLOC; }
     GeomState g = GeomState::from_chunk(chunk, (size_t)P);
 
     const size_t gx = (width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+    gs4d_note_alloc();
     char* ichunk = (char*)image_alloc(image_ctx, ImageState::required((size_t)width * height, gx * gy));
     if (!ichunk) { gs4d_set_error("image allocator returned NULL"); return GS4D_EALLOC; }
     ImageState im = ImageState::from_chunk(ichunk, (size_t)width * height, gx * gy);
@@ -404,6 +418,7 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     if (!ts.tried) {
         ts.tried = true;
         void* p = nullptr;
+        gs4d_note_alloc();
         if (getenv("GS4D_NO_MAILBOX") == nullptr &&
             hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocCoherent) == hipSuccess) {
             ts.mailbox = (unsigned long long*)p;
@@ -418,11 +433,13 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     rc = gs4d_launch_scan(P, g, ts.mailbox, seq, debug, s);
     if (rc) return rc;
 
+    const bool with_ckpt = !(debug_arg & GS4D_FORWARD_ONLY);
     char* bchunk = nullptr;
     size_t guess_R = 0;
     if (ts.last_R) {
         guess_R = ts.last_R + ts.last_R / 8 + 4096;
-        bchunk = (char*)binning_alloc(binning_ctx, BinningState::required(guess_R));
+        gs4d_note_alloc();
+        bchunk = (char*)binning_alloc(binning_ctx, BinningState::required(guess_R, with_ckpt));
         if (gs4d_trace_on()) gs4d_trace_checkpoint("binning allocator callback (speculative size)");
         if (!bchunk) {
             (void)hipStreamSynchronize(s);                                  // no post may arrive after this call has returned
@@ -478,11 +495,12 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
 
     if (!bchunk || (size_t)R > guess_R) {
         if (bchunk) ts.regrow++;
-        bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R));
+        gs4d_note_alloc();
+        bchunk = (char*)binning_alloc(binning_ctx, BinningState::required((size_t)R, with_ckpt));
         if (!bchunk) { gs4d_set_error("binning allocator returned NULL"); return GS4D_EALLOC; }
     }
     ts.last_R = (size_t)R;
-    BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
+    BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height), with_ckpt);
 
     rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);
     if (rc) return rc;
@@ -523,6 +541,7 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
     char* bchunk = binning_buffer;
     BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
 
+    gs4d_note_alloc();
     float* inst_grad = (float*)scratch_alloc(scratch_ctx, gs4d_backward_scratch_bytes(R));
     if (!inst_grad) { gs4d_set_error("backward scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)inst_grad & 255) { gs4d_set_error("backward scratch must be 256-byte aligned"); return GS4D_EINVAL; }

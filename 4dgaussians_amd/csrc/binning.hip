@@ -825,7 +825,7 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     GS4D_PROF("emit_keys", s);
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                        radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
-                       im.ranges, gx * gy, b.seg_owner, (int)b.seg_slots);
+                       im.ranges, gx * gy, b.seg_owner, b.seg_owner ? (int)b.seg_slots : 0);   // no slots on a forward-only call
     GS4D_LAUNCH_CHECK("emit_keys", debug, s);
     }
 

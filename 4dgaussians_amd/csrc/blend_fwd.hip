@@ -112,9 +112,14 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
             const float d = depths[id];
             const float r = features[3 * (size_t)id + 0], g = features[3 * (size_t)id + 1],
                         b = features[3 * (size_t)id + 2];
+            // A pixel that skips an entry blends it with weight 0 (straight-line loop body, below): 0 * Inf or 0 * NaN
+            // would poison it, where the reference's `continue` leaves it untouched.  Colours and depth are therefore
+            // staged as finite values (fmin / fmax drop a NaN; identity for every finite input) -- once per staged
+            // entry, not per visit; a pixel that does blend a diverged Gaussian still ends up non-finite or huge.
+            auto finite = [](float v) { return fminf(fmaxf(v, -3.4028235e38f), 3.4028235e38f); };
             s_a[e] = make_float4(xy.x, xy.y, co.x, co.y);
-            s_b[e] = make_float4(co.z, co.w, d, r);
-            s_c[e] = make_float2(g, b);
+            s_b[e] = make_float4(co.z, co.w, finite(d), finite(r));
+            s_c[e] = make_float2(finite(g), finite(b));
             s_box[e] = gs4d::alpha_support_box(xy, co);
         }
         __syncthreads();

@@ -17,6 +17,9 @@
 #define GS4D_CKPT_FIELDS 5
 
 void gs4d_set_error(const char* fmt, ...);
+// every request the library makes for memory -- an allocator callback or a runtime allocation of its own -- is counted
+// (gs4d_debug_alloc_calls, include/gs4d.h): the allocation-free entry point's test reads the counter around the call
+void gs4d_note_alloc();
 
 // GS4D_TRACE=1 (environment, read once): every compute entry point logs entry / exit with wall-clock times to stderr,
 // every blocking runtime call inside the library (the num_rendered wait and its copy + synchronise fall-back, debug
@@ -117,8 +120,8 @@ struct BinningState {
     int sorted;               // which ping-pong half holds the sorted lists after `passes` passes
     uint64_t* keys_sorted() const { return keys_tmp[sorted]; }
     uint32_t* point_list() const { return values_tmp[sorted]; }
-    static BinningState from_chunk(char*& chunk, size_t R, int passes);
-    static size_t required(size_t R);
+    static BinningState from_chunk(char*& chunk, size_t R, int passes, bool checkpoints = true);
+    static size_t required(size_t R, bool checkpoints = true);
 };
 
 // sort tile geometry

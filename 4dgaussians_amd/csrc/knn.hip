@@ -491,6 +491,7 @@ extern "C" int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, 
     GS4D_PROF("knn", s);
     KnnScratch k;
     const size_t bytes = knn_carve(nullptr, P, k);
+    gs4d_note_alloc();
     char* base = (char*)alloc(alloc_ctx, bytes);
     if (!base) { gs4d_set_error("knn scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)base & 255) { gs4d_set_error("knn scratch must be 256-byte aligned"); return GS4D_EINVAL; }
@@ -591,6 +592,7 @@ extern "C" int gs4d_knn_query_order(gs4d_alloc_fn alloc, void* alloc_ctx, int n,
     };
     carve(nullptr);
     const size_t bytes = (size_t)p + 256;
+    gs4d_note_alloc();
     char* base = (char*)alloc(alloc_ctx, bytes);
     if (!base) { gs4d_set_error("knn scratch allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)base & 255) { gs4d_set_error("knn scratch must be 256-byte aligned"); return GS4D_EINVAL; }

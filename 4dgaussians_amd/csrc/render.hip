@@ -156,6 +156,7 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
     }
     memset(state, 0, sizeof *state);
     const FwdArena lay = carve_forward(r, nullptr);
+    gs4d_note_alloc();
     char* base = (char*)alloc(alloc_ctx, lay.bytes);
     if (!base) { gs4d_set_error("gs4d_render_forward: the allocator returned NULL for the activation arena"); return GS4D_EALLOC; }
     if ((uintptr_t)base & 255) { gs4d_set_error("gs4d_render_forward: the arena must be 256-byte aligned"); return GS4D_EINVAL; }
@@ -215,6 +216,7 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
     if (f.bytes > st->arena_bytes) { gs4d_set_error("gs4d_render_backward: the state does not belong to this descriptor"); return GS4D_EINVAL; }
     const int R = st->num_rendered;
     const BwdArena lay = carve_backward(r, R, dL_ddepth == nullptr, nullptr);
+    gs4d_note_alloc();
     char* base = (char*)alloc(alloc_ctx, lay.bytes);
     if (!base) { gs4d_set_error("gs4d_render_backward: the allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)base & 255) { gs4d_set_error("gs4d_render_backward: the scratch must be 256-byte aligned"); return GS4D_EINVAL; }

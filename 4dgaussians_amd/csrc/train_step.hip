@@ -194,6 +194,41 @@ static int fill_terms(int nterms, const gs4d_plane_reg_term* terms, RegTerms& T,
     return GS4D_OK;
 }
 
+
+// ---------------------------------------------------------------- row gather (densify / prune surgery)
+#define GATHER_MAX_ARRAYS 32
+struct GatherBatch {
+    const uint32_t* src[GATHER_MAX_ARRAYS];
+    uint32_t* dst[GATHER_MAX_ARRAYS];
+    const uint32_t* tail[GATHER_MAX_ARRAYS];
+    int row_words[GATHER_MAX_ARRAYS];
+    int zero_fresh[GATHER_MAX_ARRAYS];
+};
+
+// grid.y = array; grid.x strides over its n_out * row_words 4-byte words: dst[i][w] = fresh[i] && zero_fresh ? 0 :
+// i >= n_out - n_tail && tail ? tail[i - (n_out - n_tail)][w] : src[index[i]][w].  Words are moved as bit patterns.
+__global__ __launch_bounds__(256) void gather_rows_kernel(GatherBatch B, long long n_out, int n_tail,
+                                                          const long long* __restrict__ index,
+                                                          const unsigned char* __restrict__ fresh)
+{
+    const int a = blockIdx.y;
+    const int rw = B.row_words[a];
+    const uint32_t* __restrict__ src = B.src[a];
+    uint32_t* __restrict__ dst = B.dst[a];
+    const uint32_t* __restrict__ tail = B.tail[a];
+    const bool zf = B.zero_fresh[a] != 0;
+    const long long total = n_out * rw, tail0 = n_out - n_tail;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / rw;
+        const int w = (int)(e - i * rw);
+        uint32_t v;
+        if (zf && fresh && fresh[i]) v = 0u;
+        else if (tail && i >= tail0) v = tail[(i - tail0) * rw + w];
+        else v = src[index[i] * rw + w];
+        dst[e] = v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -230,6 +265,38 @@ int gs4d_adamw_step(int ntensors, const gs4d_adamw_tensor* tensors, double beta1
         hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, s, B, (float)(1.0 - beta1), (float)beta2,
                            (float)(1.0 - beta2), (float)eps);
         GS4D_LAUNCH_CHECK("adamw", 0, s);
+    }
+    return GS4D_OK;
+}
+
+int gs4d_gather_rows(long long n_out, const long long* index, const unsigned char* fresh, int n_tail, int narrays,
+                     const gs4d_gather_array* arrays, long long n_src, void* stream)
+{
+    GS4D_TRACE_SCOPE("gs4d_gather_rows");
+    hipStream_t s = (hipStream_t)stream;
+    if (n_out < 0 || n_tail < 0 || n_tail > n_out || narrays < 0 || (narrays > 0 && !arrays) || (n_out > 0 && !index) || n_src < 0) {
+        gs4d_set_error("gs4d_gather_rows: bad sizes or null pointer");
+        return GS4D_EINVAL;
+    }
+    if (n_out == 0 || narrays == 0) return GS4D_OK;
+    for (int base = 0; base < narrays; base += GATHER_MAX_ARRAYS) {
+        GatherBatch B = {};
+        const int cnt = narrays - base < GATHER_MAX_ARRAYS ? narrays - base : GATHER_MAX_ARRAYS;
+        long long wmax = 0;
+        for (int i = 0; i < cnt; i++) {
+            const gs4d_gather_array& a = arrays[base + i];
+            if (!a.dst || a.row_words <= 0 || (!a.src && n_src > 0)) {
+                gs4d_set_error("gs4d_gather_rows: array %d has a null pointer or an empty row", base + i);
+                return GS4D_EINVAL;
+            }
+            B.src[i] = (const uint32_t*)a.src; B.dst[i] = (uint32_t*)a.dst; B.tail[i] = (const uint32_t*)a.tail;
+            B.row_words[i] = a.row_words; B.zero_fresh[i] = a.zero_fresh;
+            wmax = n_out * a.row_words > wmax ? n_out * a.row_words : wmax;
+        }
+        long long gx = (wmax + 255) / 256;
+        gx = gx < 1 ? 1 : (gx > 4096 ? 4096 : gx);
+        hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)gx, cnt), dim3(256), 0, s, B, n_out, n_tail, index, fresh);
+        GS4D_LAUNCH_CHECK("gather_rows", 0, s);
     }
     return GS4D_OK;
 }

@@ -99,10 +99,13 @@ class FusedAdamW(torch.optim.Optimizer):
                 loss = closure()
         L = _cabi.lib()
         active = [(gi, p) for gi, group in enumerate(self.param_groups) for p in group["params"] if p.grad is not None]
-        sig = [(id(p), id(self.state[p])) if p in self.state else (id(p), 0) for _, p in active]
+        # the plan batches the parameters by (betas, eps) of their group: a later change to those is a new plan, as
+        # torch.optim.AdamW honours it on the next step (lr and weight_decay are re-read every step below)
+        hyper = [(float(g["betas"][0]), float(g["betas"][1]), float(g["eps"])) for g in self.param_groups]
+        sig = [(id(p), id(self.state[p])) if p in self.state else (id(p), 0) for _, p in active] + hyper
         if sig != self._sig:
             self._plan = self._build_plan(active)
-            self._sig = [(id(p), id(self.state[p])) for _, p in active]
+            self._sig = [(id(p), id(self.state[p])) for _, p in active] + hyper
         lrs = np.array([float(g["lr"]) for g in self.param_groups])
         wds = np.array([float(g["weight_decay"]) for g in self.param_groups])
         for b in self._plan:
@@ -123,9 +126,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 pp.append(p.data_ptr()); gp.append(g.data_ptr()); mp.append(m.data_ptr()); vp.append(v.data_ptr())
             rec["param"], rec["grad"], rec["exp_avg"], rec["exp_avg_sq"] = pp, gp, mp, vp
             rec["lr"], rec["weight_decay"] = lrs[b["gidx"]], wds[b["gidx"]]
-            steps = b["steps"]
-            steps += 1.0
-            b["base"] += 1.0
+            steps = b["steps"] + 1.0            # committed (with the state's step tensors) only once the launch succeeded
             if steps[0] == steps[-1] and (steps == steps[0]).all():         # one value unless parameters joined later
                 rec["bias_correction1"] = 1.0 - beta1 ** float(steps[0])
                 rec["bias_correction2"] = 1.0 - beta2 ** float(steps[0])
@@ -137,5 +138,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 rc = L.gs4d_adamw_step(C.c_int(len(rec)), C.c_void_p(rec.ctypes.data), C.c_double(beta1), C.c_double(beta2),
                                        C.c_double(eps), _cabi.current_stream(dev))
             _cabi.check(rc, "gs4d_adamw_step")
+            b["steps"] = steps
+            b["base"] += 1.0
             del keep
         return loss

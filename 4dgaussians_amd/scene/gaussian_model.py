@@ -19,6 +19,7 @@ be exercised without a GPU (tests); the defaults are the HIP path.
 """
 from __future__ import annotations
 
+import math
 import os
 from collections import namedtuple
 
@@ -41,35 +42,99 @@ def inverse_sigmoid(x):                      # utils/general_utils.py:19-20
     return torch.log(x / (1 - x))
 
 
-def build_rotation(r):                       # utils/general_utils.py:86-107
-    norm = torch.sqrt(r[:, 0] * r[:, 0] + r[:, 1] * r[:, 1] + r[:, 2] * r[:, 2] + r[:, 3] * r[:, 3])
-    q = r / norm[:, None]
-    R = torch.zeros((q.size(0), 3, 3), device=r.device)
-    r_, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
-    R[:, 0, 0] = 1 - 2 * (y * y + z * z)
-    R[:, 0, 1] = 2 * (x * y - r_ * z)
-    R[:, 0, 2] = 2 * (x * z + r_ * y)
-    R[:, 1, 0] = 2 * (x * y + r_ * z)
-    R[:, 1, 1] = 1 - 2 * (x * x + z * z)
-    R[:, 1, 2] = 2 * (y * z - r_ * x)
-    R[:, 2, 0] = 2 * (x * z - r_ * y)
-    R[:, 2, 1] = 2 * (y * z + r_ * x)
-    R[:, 2, 2] = 1 - 2 * (x * x + y * y)
-    return R
+def build_rotation(r):
+    """(w, x, y, z) quaternion rows, normalised here, -> rotation matrices [n, 3, 3] (what utils/general_utils.py:86-107
+    returns), written as R = (1 - 2|v|^2) I + 2 v v^T + 2 w [v]x for the unit quaternion (w, v)."""
+    q = r / torch.sqrt((r * r).sum(dim=1, keepdim=True))
+    w, v = q[:, 0], q[:, 1:]
+    cross = torch.zeros((q.shape[0], 3, 3), dtype=r.dtype, device=r.device)          # [v]x
+    cross[:, 0, 1], cross[:, 0, 2], cross[:, 1, 2] = -v[:, 2], v[:, 1], -v[:, 0]
+    cross = cross - cross.transpose(1, 2)
+    eye = torch.eye(3, dtype=r.dtype, device=r.device)
+    return (1.0 - 2.0 * (v * v).sum(dim=1))[:, None, None] * eye + 2.0 * v[:, :, None] * v[:, None, :] + 2.0 * w[:, None, None] * cross
+
+
+class _LogLinearSchedule:
+    """lr(step): log-linear interpolation from lr_init (step 0) to lr_final (step max_steps), scaled during the first
+    lr_delay_steps by a sine ramp from lr_delay_mult to 1; 0 before step 0 and when both ends are 0 -- the schedule of
+    utils/general_utils.py:36-70."""
+
+    def __init__(self, lr_init, lr_final, lr_delay_steps, lr_delay_mult, max_steps):
+        self.off = lr_init == 0.0 and lr_final == 0.0
+        self.log_ends = (None, None) if self.off else (math.log(lr_init), math.log(lr_final))
+        self.delay_steps, self.delay_mult, self.max_steps = lr_delay_steps, lr_delay_mult, max_steps
+
+    def __call__(self, step):
+        if self.off or step < 0:
+            return 0.0
+        t = min(max(step / self.max_steps, 0.0), 1.0)
+        lr = math.exp(self.log_ends[0] * (1 - t) + self.log_ends[1] * t)
+        if self.delay_steps > 0:
+            ramp = math.sin(0.5 * math.pi * min(max(step / self.delay_steps, 0.0), 1.0))
+            lr *= self.delay_mult + (1 - self.delay_mult) * ramp
+        return lr
 
 
 def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
-    """utils/general_utils.py:36-70: log-linear interpolation from lr_init to lr_final with an optional warm-up."""
-    def helper(step):
-        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
-            return 0.0
-        if lr_delay_steps > 0:
-            delay_rate = lr_delay_mult + (1 - lr_delay_mult) * np.sin(0.5 * np.pi * np.clip(step / lr_delay_steps, 0, 1))
-        else:
-            delay_rate = 1.0
-        t = np.clip(step / max_steps, 0, 1)
-        return delay_rate * np.exp(np.log(lr_init) * (1 - t) + np.log(lr_final) * t)
-    return helper
+    return _LogLinearSchedule(lr_init, lr_final, lr_delay_steps, lr_delay_mult, max_steps)
+
+
+# optimizer group name -> attribute, for the six per-Gaussian parameter tensors (one tensor per group), and the
+# per-Gaussian statistics that follow the rows of the model
+_POINT_PARAMS = (("xyz", "_xyz"), ("f_dc", "_features_dc"), ("f_rest", "_features_rest"), ("opacity", "_opacity"),
+                 ("scaling", "_scaling"), ("rotation", "_rotation"))
+_POINT_STATS = ("xyz_gradient_accum", "denom", "max_radii2D", "_deformation_accum")
+
+
+def _gather_rows(sources, index, fresh, tails, zero_fresh):
+    """One row gather over several per-Gaussian arrays (gs4d_gather_rows, include/gs4d.h): output row i of every array
+    is input row index[i]; arrays flagged in zero_fresh get zeros in rows where fresh is set; an array with a tail takes
+    its last len(tail) rows from it.  HIP tensors: ONE launch over a pointer table.  CPU tensors (the host-logic
+    tests): the same definition with torch indexing."""
+    n_out = int(index.numel())
+    outs = [torch.empty((n_out,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device) for t in sources]
+    if not sources or n_out == 0:
+        return outs
+    dev = sources[0].device
+    n_tail = max([0] + [int(t.shape[0]) for t in tails if t is not None])
+    if dev.type != "cuda":
+        for o, t, tl, zf in zip(outs, sources, tails, zero_fresh):
+            o.copy_(t.index_select(0, index))
+            if tl is not None:
+                o[n_out - tl.shape[0]:] = tl
+            if zf and fresh is not None:
+                o[fresh] = 0
+        return outs
+    import ctypes as C
+    from .. import _cabi
+
+    class GatherArray(C.Structure):
+        _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("tail", C.c_void_p), ("row_words", C.c_int), ("zero_fresh", C.c_int)]
+
+    keep, table = [], (GatherArray * len(sources))()
+    for k, (o, t, tl, zf) in enumerate(zip(outs, sources, tails, zero_fresh)):
+        if t.element_size() != 4:
+            raise RuntimeError("gs4d_gather_rows moves 4-byte elements")
+        t = t.contiguous()
+        if tl is not None:
+            if tl.shape[0] != n_tail:
+                raise RuntimeError("every tail of one gather must have the same number of rows")
+            tl = tl.to(dtype=t.dtype).contiguous()
+        keep += [t, tl]
+        words = 1
+        for d in t.shape[1:]:
+            words *= int(d)
+        table[k].src, table[k].dst = t.data_ptr() if t.numel() else None, o.data_ptr()
+        table[k].tail = tl.data_ptr() if tl is not None and tl.numel() else None
+        table[k].row_words, table[k].zero_fresh = words, int(bool(zf))
+    index = index.to(dtype=torch.int64).contiguous()
+    fresh_u8 = None if fresh is None else fresh.to(torch.uint8).contiguous()
+    with torch.cuda.device(dev):
+        rc = _cabi.lib().gs4d_gather_rows(C.c_longlong(n_out), _cabi.ptr(index), _cabi.ptr(fresh_u8), C.c_int(n_tail),
+                                          C.c_int(len(sources)), table, C.c_longlong(int(sources[0].shape[0])),
+                                          _cabi.current_stream(dev))
+    _cabi.check(rc, "gs4d_gather_rows")
+    return outs
 
 
 # ---------------------------------------------------------------- PLY (binary little endian / ascii, float properties)
@@ -205,60 +270,53 @@ class GaussianModel:
 
     # ---- initialisation (scene/__init__.py:60)
     def create_from_pcd(self, pcd, spatial_lr_scale: float, time_line: int = 0):
+        """Point cloud -> initial Gaussians (scene/gaussian_model.py:159-185): positions = the points, DC colour = the
+        point colours as SH band 0, every other SH coefficient 0, isotropic log-scale = log of the root mean squared
+        distance to the 3 nearest neighbours (distCUDA2, clamped at 1e-7), identity rotation, opacity logit(0.1)."""
         from ..simple_knn._C import distCUDA2
         dev = self.device
+        as_f32 = lambda a: torch.as_tensor(np.asarray(a)).to(dtype=torch.float32, device=dev)
+        points = as_f32(pcd.points).contiguous()
+        n, coeffs = points.shape[0], (self.max_sh_degree + 1) ** 2
+        leaf = lambda t: nn.Parameter(t.contiguous().requires_grad_(True))
         self.spatial_lr_scale = spatial_lr_scale
-        pts = torch.tensor(np.asarray(pcd.points)).to(dtype=torch.float32, device=dev)
-        fused_color = RGB2SH(torch.tensor(np.asarray(pcd.colors)).to(dtype=torch.float32, device=dev))
-        features = torch.zeros((fused_color.shape[0], 3, (self.max_sh_degree + 1) ** 2), dtype=torch.float32, device=dev)
-        features[:, :3, 0] = fused_color
-        dist2 = torch.clamp_min(distCUDA2(pts.contiguous()), 0.0000001)
-        scales = torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
-        rots = torch.zeros((pts.shape[0], 4), device=dev)
-        rots[:, 0] = 1
-        opacities = inverse_sigmoid(0.1 * torch.ones((pts.shape[0], 1), dtype=torch.float32, device=dev))
-        self._xyz = nn.Parameter(pts.requires_grad_(True))
         self._deformation = self._deformation.to(dev)
-        self._features_dc = nn.Parameter(features[:, :, 0:1].transpose(1, 2).contiguous().requires_grad_(True))
-        self._features_rest = nn.Parameter(features[:, :, 1:].transpose(1, 2).contiguous().requires_grad_(True))
-        self._scaling = nn.Parameter(scales.requires_grad_(True))
-        self._rotation = nn.Parameter(rots.requires_grad_(True))
-        self._opacity = nn.Parameter(opacities.requires_grad_(True))
-        self.max_radii2D = torch.zeros((pts.shape[0]), device=dev)
-        self._deformation_table = torch.gt(torch.ones((pts.shape[0]), device=dev), 0)
+        self._xyz = leaf(points)
+        self._features_dc = leaf(RGB2SH(as_f32(pcd.colors)).reshape(n, 1, 3))
+        self._features_rest = leaf(torch.zeros((n, coeffs - 1, 3), dtype=torch.float32, device=dev))
+        spacing = torch.sqrt(torch.clamp_min(distCUDA2(points), 1e-7))
+        self._scaling = leaf(torch.log(spacing)[:, None].expand(n, 3))
+        identity = torch.zeros((n, 4), dtype=torch.float32, device=dev)
+        identity[:, 0] = 1.0
+        self._rotation = leaf(identity)
+        self._opacity = leaf(inverse_sigmoid(torch.full((n, 1), 0.1, dtype=torch.float32, device=dev)))
+        self.max_radii2D = torch.zeros(n, device=dev)
+        self._deformation_table = torch.ones(n, dtype=torch.bool, device=dev)
 
     # ---- optimizer
     def training_setup(self, training_args):
-        dev = self._xyz.device
-        n = self.get_xyz.shape[0]
-        self.percent_dense = training_args.percent_dense
-        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
-        self.denom = torch.zeros((n, 1), device=dev)
+        """Eight AdamW groups with the reference's names, order and learning rates (scene/gaussian_model.py:188-225):
+        the three spatial rates scale with spatial_lr_scale, f_rest trains at feature_lr / 20."""
+        a, s = training_args, self.spatial_lr_scale
+        dev, n = self._xyz.device, self._xyz.shape[0]
+        self.percent_dense = a.percent_dense
+        self.xyz_gradient_accum, self.denom = torch.zeros((n, 1), device=dev), torch.zeros((n, 1), device=dev)
         self._deformation_accum = torch.zeros((n, 3), device=dev)
-        s = self.spatial_lr_scale
-        l = [
-            {"params": [self._xyz], "lr": training_args.position_lr_init * s, "name": "xyz"},
-            {"params": list(self._deformation.get_mlp_parameters()), "lr": training_args.deformation_lr_init * s, "name": "deformation"},
-            {"params": list(self._deformation.get_grid_parameters()), "lr": training_args.grid_lr_init * s, "name": "grid"},
-            {"params": [self._features_dc], "lr": training_args.feature_lr, "name": "f_dc"},
-            {"params": [self._features_rest], "lr": training_args.feature_lr / 20.0, "name": "f_rest"},
-            {"params": [self._opacity], "lr": training_args.opacity_lr, "name": "opacity"},
-            {"params": [self._scaling], "lr": training_args.scaling_lr, "name": "scaling"},
-            {"params": [self._rotation], "lr": training_args.rotation_lr, "name": "rotation"},
-        ]
+        rates = {"xyz": a.position_lr_init * s, "deformation": a.deformation_lr_init * s, "grid": a.grid_lr_init * s,
+                 "f_dc": a.feature_lr, "f_rest": a.feature_lr / 20.0, "opacity": a.opacity_lr, "scaling": a.scaling_lr,
+                 "rotation": a.rotation_lr}
+        members = {"deformation": list(self._deformation.get_mlp_parameters()), "grid": list(self._deformation.get_grid_parameters())}
+        members.update({name: [getattr(self, attr)] for name, attr in _POINT_PARAMS})
+        order = ("xyz", "deformation", "grid", "f_dc", "f_rest", "opacity", "scaling", "rotation")
+        groups = [{"params": members[name], "lr": rates[name], "name": name} for name in order]
         cls = self._optimizer_cls
         if cls is None:
             from ..optim import FusedAdamW as cls
-        self.optimizer = cls(l, lr=0.0001, eps=1e-8)
-        self.xyz_scheduler_args = get_expon_lr_func(training_args.position_lr_init * s, training_args.position_lr_final * s,
-                                                    lr_delay_mult=training_args.position_lr_delay_mult,
-                                                    max_steps=training_args.position_lr_max_steps)
-        self.deformation_scheduler_args = get_expon_lr_func(training_args.deformation_lr_init * s, training_args.deformation_lr_final * s,
-                                                            lr_delay_mult=training_args.deformation_lr_delay_mult,
-                                                            max_steps=training_args.position_lr_max_steps)
-        self.grid_scheduler_args = get_expon_lr_func(training_args.grid_lr_init * s, training_args.grid_lr_final * s,
-                                                     lr_delay_mult=training_args.deformation_lr_delay_mult,
-                                                     max_steps=training_args.position_lr_max_steps)
+        self.optimizer = cls(groups, lr=0.0001, eps=1e-8)
+        schedule = lambda lr0, lr1, mult: get_expon_lr_func(lr0 * s, lr1 * s, lr_delay_mult=mult, max_steps=a.position_lr_max_steps)
+        self.xyz_scheduler_args = schedule(a.position_lr_init, a.position_lr_final, a.position_lr_delay_mult)
+        self.deformation_scheduler_args = schedule(a.deformation_lr_init, a.deformation_lr_final, a.deformation_lr_delay_mult)
+        self.grid_scheduler_args = schedule(a.grid_lr_init, a.grid_lr_final, a.deformation_lr_delay_mult)
 
     def update_learning_rate(self, iteration):
         for group in self.optimizer.param_groups:
@@ -347,109 +405,156 @@ class GaussianModel:
                 out[name] = new
         return out
 
-    def _prune_optimizer(self, mask):
-        out = {}
-        for group in self.optimizer.param_groups:
-            if len(group["params"]) > 1:
+    # Every edit of the set of Gaussians -- prune, clone, split, a spatial re-ordering -- is ONE index vector: row i of the
+    # edited model is row index[i] of the current one.  _resample applies it to the six parameter tensors, their Adam
+    # moments and the per-Gaussian statistics with a single gather (gs4d_gather_rows), where the reference copies masks
+    # and concatenates tensor by tensor (scene/gaussian_model.py:356-432).  The results are the reference's: parameters
+    # and moments of surviving rows are carried over bit for bit, new rows start with zero moments, densification
+    # resets the statistics, pruning keeps them.
+    def _resample(self, index, fresh=None, tails=None, reset_stats=False):
+        tails = tails or {}
+        n_src, n_out = self._xyz.shape[0], int(index.numel())
+        groups = {} if self.optimizer is None else {g["name"]: g for g in self.optimizer.param_groups if len(g["params"]) == 1}
+        sources, tail_list, zero_fresh, slots = [], [], [], []
+        for name, attr in _POINT_PARAMS:
+            old = getattr(self, attr)
+            sources.append(old.detach()); tail_list.append(tails.get(name)); zero_fresh.append(False); slots.append(("param", name, attr))
+            state = self.optimizer.state.get(old) if name in groups else None
+            if state:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    sources.append(state[key]); tail_list.append(None); zero_fresh.append(True); slots.append((key, name, attr))
+        if not reset_stats:
+            for attr in _POINT_STATS:
+                t = getattr(self, attr)
+                if t.dim() and t.shape[0] == n_src:
+                    t2 = t if t.dim() > 1 else t[:, None]
+                    sources.append(t2); tail_list.append(None); zero_fresh.append(True); slots.append(("stat", attr, t.dim()))
+        outs = _gather_rows(sources, index, fresh, tail_list, zero_fresh)
+        moments = {}
+        for (kind, name, attr), out in zip(slots, outs):
+            if kind == "stat":
+                setattr(self, name, out if attr > 1 else out[:, 0])
+            elif kind != "param":
+                moments[(name, kind)] = out
+        for (kind, name, attr), out in zip(slots, outs):
+            if kind != "param":
                 continue
-            old = group["params"][0]
-            stored = self.optimizer.state.get(old, None)
-            new = nn.Parameter(old.detach()[mask].clone().requires_grad_(True))
-            if stored is not None and len(stored):
-                stored["exp_avg"] = stored["exp_avg"][mask]
-                stored["exp_avg_sq"] = stored["exp_avg_sq"][mask]
-                del self.optimizer.state[old]
-                self.optimizer.state[new] = stored
-            group["params"][0] = new
-            out[group["name"]] = new
-        return out
+            old, new = getattr(self, attr), nn.Parameter(out.requires_grad_(True))
+            if name in groups:
+                state = self.optimizer.state.pop(old, None)
+                if state is not None:
+                    if state:
+                        state["exp_avg"], state["exp_avg_sq"] = moments[(name, "exp_avg")], moments[(name, "exp_avg_sq")]
+                    self.optimizer.state[new] = state
+                groups[name]["params"][0] = new
+            setattr(self, attr, new)
+        self._deformation_table = self._deformation_table[index] if self._deformation_table.shape[0] == n_src else self._deformation_table
+        if reset_stats:
+            dev = self._xyz.device
+            self.xyz_gradient_accum, self.denom = torch.zeros((n_out, 1), device=dev), torch.zeros((n_out, 1), device=dev)
+            self._deformation_accum, self.max_radii2D = torch.zeros((n_out, 3), device=dev), torch.zeros(n_out, device=dev)
 
-    def _adopt(self, t):
-        self._xyz, self._features_dc, self._features_rest = t["xyz"], t["f_dc"], t["f_rest"]
-        self._opacity, self._scaling, self._rotation = t["opacity"], t["scaling"], t["rotation"]
+    def _rows(self, n=None):
+        return torch.arange(self._xyz.shape[0] if n is None else n, device=self._xyz.device)
 
     def prune_points(self, mask):
-        valid = ~mask
-        self._adopt(self._prune_optimizer(valid))
-        self._deformation_accum = self._deformation_accum[valid]
-        self.xyz_gradient_accum = self.xyz_gradient_accum[valid]
-        self._deformation_table = self._deformation_table[valid]
-        self.denom = self.denom[valid]
-        self.max_radii2D = self.max_radii2D[valid]
-
-    def cat_tensors_to_optimizer(self, tensors_dict):
-        out = {}
-        for group in self.optimizer.param_groups:
-            if len(group["params"]) > 1:
-                continue
-            ext = tensors_dict[group["name"]]
-            old = group["params"][0]
-            stored = self.optimizer.state.get(old, None)
-            new = nn.Parameter(torch.cat((old.detach(), ext.detach()), dim=0).requires_grad_(True))
-            if stored is not None and len(stored):
-                stored["exp_avg"] = torch.cat((stored["exp_avg"], torch.zeros_like(ext)), dim=0)
-                stored["exp_avg_sq"] = torch.cat((stored["exp_avg_sq"], torch.zeros_like(ext)), dim=0)
-                del self.optimizer.state[old]
-                self.optimizer.state[new] = stored
-            group["params"][0] = new
-            out[group["name"]] = new
-        return out
+        """Drop the rows where mask is set (scene/gaussian_model.py:376-389); statistics and moments follow."""
+        self._resample(torch.nonzero(~mask, as_tuple=False).squeeze(1))
 
     def densification_postfix(self, new_xyz, new_features_dc, new_features_rest, new_opacities, new_scaling, new_rotation,
                               new_deformation_table):
-        d = {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
-             "scaling": new_scaling, "rotation": new_rotation}
-        self._adopt(self.cat_tensors_to_optimizer(d))
-        dev, n = self._xyz.device, self.get_xyz.shape[0]
-        self._deformation_table = torch.cat([self._deformation_table, new_deformation_table], -1)
-        self.xyz_gradient_accum = torch.zeros((n, 1), device=dev)
-        self._deformation_accum = torch.zeros((n, 3), device=dev)
-        self.denom = torch.zeros((n, 1), device=dev)
-        self.max_radii2D = torch.zeros((n), device=dev)
+        """Append explicitly given rows (scene/gaussian_model.py:412-432): zero moments, statistics reset."""
+        n, k = self._xyz.shape[0], new_xyz.shape[0]
+        dev = self._xyz.device
+        index = torch.cat((self._rows(), torch.zeros(k, dtype=torch.long, device=dev)))
+        fresh = torch.cat((torch.zeros(n, dtype=torch.bool, device=dev), torch.ones(k, dtype=torch.bool, device=dev)))
+        table = torch.cat((self._deformation_table, new_deformation_table.to(self._deformation_table.dtype)), -1)
+        self._resample(index, fresh, {"xyz": new_xyz, "f_dc": new_features_dc, "f_rest": new_features_rest, "opacity": new_opacities,
+                                      "scaling": new_scaling, "rotation": new_rotation}, reset_stats=True)
+        self._deformation_table = table
+
+    def _clone_selection(self, grads, grad_threshold, scene_extent):
+        """Small Gaussians (largest scale <= percent_dense * extent) whose accumulated screen-space gradient norm reaches the
+        threshold (scene/gaussian_model.py:460-470)."""
+        return (torch.norm(grads, dim=-1) >= grad_threshold) & (self.get_scaling.max(dim=1).values <= self.percent_dense * scene_extent)
+
+    def _split_and_apply(self, index, fresh, grads, grad_threshold, scene_extent, N):
+        """index / fresh describe the model an earlier step leaves (identity, or originals + clones); large Gaussians of THAT
+        model (largest scale > percent_dense * extent, gradient at the threshold; rows beyond the gradient vector count
+        as 0) are replaced by N samples each, drawn from the Gaussian itself, with scales / (0.8 N)
+        (scene/gaussian_model.py:434-458).  One gather applies everything."""
+        dev = self._xyz.device
+        scales = self.get_scaling[index]
+        padded = torch.zeros(index.numel(), device=dev)
+        padded[:grads.shape[0]] = grads.squeeze()
+        sel = (padded >= grad_threshold) & (scales.max(dim=1).values > self.percent_dense * scene_extent)
+        k = int(sel.sum())
+        if k == 0:
+            return index, fresh, None
+        rows = index[sel]
+        stds = scales[sel].repeat(N, 1)
+        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
+        frames = build_rotation(self._rotation[rows]).repeat(N, 1, 1)
+        new_xyz = torch.bmm(frames, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[rows].repeat(N, 1)
+        new_scaling = self.scaling_inverse_activation(stds / (0.8 * N))
+        index = torch.cat((index[~sel], rows.repeat(N)))
+        fresh = torch.cat((fresh[~sel], torch.ones(N * k, dtype=torch.bool, device=dev)))
+        return index, fresh, {"xyz": new_xyz, "scaling": new_scaling}
 
     @torch.no_grad()
     def densify_and_split(self, grads, grad_threshold, scene_extent, N=2):
-        dev = self._xyz.device
-        n_init = self.get_xyz.shape[0]
-        padded_grad = torch.zeros((n_init), device=dev)
-        padded_grad[:grads.shape[0]] = grads.squeeze()
-        sel = torch.where(padded_grad >= grad_threshold, True, False)
-        sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values > self.percent_dense * scene_extent)
-        if not sel.any():
-            return
-        stds = self.get_scaling[sel].repeat(N, 1)
-        samples = torch.normal(mean=torch.zeros((stds.size(0), 3), device=dev), std=stds)
-        rots = build_rotation(self._rotation[sel]).repeat(N, 1, 1)
-        new_xyz = torch.bmm(rots, samples.unsqueeze(-1)).squeeze(-1) + self.get_xyz[sel].repeat(N, 1)
-        new_scaling = self.scaling_inverse_activation(self.get_scaling[sel].repeat(N, 1) / (0.8 * N))
-        self.densification_postfix(new_xyz, self._features_dc[sel].repeat(N, 1, 1), self._features_rest[sel].repeat(N, 1, 1),
-                                   self._opacity[sel].repeat(N, 1), new_scaling, self._rotation[sel].repeat(N, 1),
-                                   self._deformation_table[sel].repeat(N))
-        prune_filter = torch.cat((sel, torch.zeros(N * int(sel.sum()), device=dev, dtype=torch.bool)))
-        self.prune_points(prune_filter)
+        n = self._xyz.shape[0]
+        index, fresh, tails = self._split_and_apply(self._rows(), torch.zeros(n, dtype=torch.bool, device=self._xyz.device),
+                                                    grads, grad_threshold, scene_extent, N)
+        if tails is not None:
+            self._resample(index, fresh, tails, reset_stats=True)
 
     @torch.no_grad()
     def densify_and_clone(self, grads, grad_threshold, scene_extent, *unused, **unused_kw):
-        sel = torch.where(torch.norm(grads, dim=-1) >= grad_threshold, True, False)
-        sel = torch.logical_and(sel, torch.max(self.get_scaling, dim=1).values <= self.percent_dense * scene_extent)
-        self.densification_postfix(self._xyz[sel], self._features_dc[sel], self._features_rest[sel], self._opacity[sel],
-                                   self._scaling[sel], self._rotation[sel], self._deformation_table[sel])
+        n, dev = self._xyz.shape[0], self._xyz.device
+        picked = torch.nonzero(self._clone_selection(grads, grad_threshold, scene_extent), as_tuple=False).squeeze(1)
+        fresh = torch.cat((torch.zeros(n, dtype=torch.bool, device=dev), torch.ones(picked.numel(), dtype=torch.bool, device=dev)))
+        self._resample(torch.cat((self._rows(), picked)), fresh, reset_stats=True)
 
     @torch.no_grad()
     def prune(self, max_grad, min_opacity, extent, max_screen_size):
-        prune_mask = (self.get_opacity < min_opacity).squeeze()
+        """Drop transparent Gaussians and, once max_screen_size is given, those too large on screen or in the world
+        (scene/gaussian_model.py:583-591)."""
+        doomed = (self.get_opacity < min_opacity).squeeze()
         if max_screen_size:
-            prune_mask = torch.logical_or(prune_mask, self.max_radii2D > max_screen_size)
-            prune_mask = torch.logical_or(prune_mask, self.get_scaling.max(dim=1).values > 0.1 * extent)
-        self.prune_points(prune_mask)
+            doomed = doomed | (self.max_radii2D > max_screen_size) | (self.get_scaling.max(dim=1).values > 0.1 * extent)
+        self.prune_points(doomed)
 
     @torch.no_grad()
     def densify(self, max_grad, min_opacity, extent, max_screen_size, density_threshold=5, displacement_scale=5,
                 model_path=None, iteration=None, stage=None):
+        """Clone, then split (scene/gaussian_model.py:593-597), as ONE gather: the split is decided on the model the clone
+        step leaves (originals followed by the clones, whose padded gradient is 0) and composed with it."""
         grads = self.xyz_gradient_accum / self.denom
         grads[grads.isnan()] = 0.0
-        self.densify_and_clone(grads, max_grad, extent)
-        self.densify_and_split(grads, max_grad, extent)
+        n, dev = self._xyz.shape[0], self._xyz.device
+        picked = torch.nonzero(self._clone_selection(grads, max_grad, extent), as_tuple=False).squeeze(1)
+        index = torch.cat((self._rows(), picked))
+        fresh = torch.cat((torch.zeros(n, dtype=torch.bool, device=dev), torch.ones(picked.numel(), dtype=torch.bool, device=dev)))
+        index, fresh, tails = self._split_and_apply(index, fresh, grads, max_grad, extent, 2)
+        self._resample(index, fresh, tails, reset_stats=True)
+
+    @torch.no_grad()
+    def reorder_spatially(self, bits: int = 10):
+        """Optional (no reference counterpart): store the Gaussians in the Morton order of their positions, so that
+        neighbouring rows are neighbours in space -- the HexPlane gathers and the kNN regularisers then touch nearby plane
+        texels / records together.  A pure permutation through the same gather as every other edit:
+        parameters, moments and statistics move with their rows; renders are unchanged up to the order of tile-list ties."""
+        xyz = self._xyz.detach()
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
+        code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
+        for b in range(bits):
+            for axis in range(3):
+                code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
+        order = torch.argsort(code, stable=True)
+        self._resample(order)
+        return order
 
     @torch.no_grad()
     def add_densification_stats(self, viewspace_point_tensor, update_filter):

@@ -181,6 +181,7 @@ int gs4d_state_view_get(int P, int R, int width, int height,
 /* Sizes of the three chunks (what the allocator callbacks will be asked for). */
 size_t gs4d_geometry_bytes(int P);
 size_t gs4d_binning_bytes(int R);
+size_t gs4d_binning_bytes_forward_only(int R);   /* a GS4D_FORWARD_ONLY call: no segment checkpoints are reserved */
 size_t gs4d_image_bytes(int width, int height);
 size_t gs4d_backward_scratch_bytes(int R);
 
@@ -206,6 +207,10 @@ int gs4d_knn_mean_dist2(gs4d_alloc_fn alloc, void* alloc_ctx, int P, const float
  * zero (every array is written in full before it is read), so stale contents of an earlier, larger call are harmless.
  */
 int gs4d_knn_static_max_points(void);
+/* Debug accessor (no reference counterpart): how many times, process-wide, the library has asked for memory so far -- a
+ * caller's allocator callback or a runtime allocation of its own (the pinned num_rendered mailbox is the only one).
+ * The counter does not move across gs4d_knn_mean_dist2_static (tests/test_zz_no_alloc.py). */
+unsigned long long gs4d_debug_alloc_calls(void);
 int gs4d_knn_mean_dist2_static(int P, const float* points, float* mean_dist2, void* stream);
 
 /*
@@ -476,6 +481,28 @@ int gs4d_plane_reg_forward(int nterms, const gs4d_plane_reg_term* terms /* host 
                            void* stream);
 int gs4d_plane_reg_backward(int nterms, const gs4d_plane_reg_term* terms /* host array */, const float* g_loss,
                             void* stream);
+
+/* ---- densify / clone / split / prune as ONE row gather ----
+ * The reference edits the per-Gaussian state tensor by tensor: boolean-mask copies in prune_points / _prune_optimizer
+ * (scene/gaussian_model.py:356-389), torch.cat of parameters and of zero-filled Adam moments in cat_tensors_to_optimizer /
+ * densification_postfix (:391-432), once for the clones and once more for the splits followed by a prune (:434-498).
+ * Here a model edit is one index vector -- output row i takes input row index[i] -- applied to every per-Gaussian
+ * array (six parameters, their two Adam moments each, the statistics) in one launch:
+ *   dst[i] = 0                                   if fresh[i] and the array has zero_fresh set (Adam moments of new rows)
+ *          = tail[i - (n_out - n_tail)]          if i is one of the last n_tail rows and the array has a tail
+ *                                                 (positions / log-scales of the split's new Gaussians)
+ *          = src[index[i]]                       otherwise
+ * Rows are row_words 4-byte words, moved as bit patterns (float32 or int32 alike).  index [n_out] int64 with values in
+ * [0, n_src) (NOT range-checked), fresh [n_out] bytes or NULL; `arrays` is a HOST array; all other pointers device. */
+typedef struct gs4d_gather_array {
+    const void* src;          /* [n_src][row_words] */
+    void* dst;                /* [n_out][row_words], must not overlap src */
+    const void* tail;         /* [n_tail][row_words] or NULL */
+    int row_words;
+    int zero_fresh;
+} gs4d_gather_array;
+int gs4d_gather_rows(long long n_out, const long long* index, const unsigned char* fresh, int n_tail, int narrays,
+                     const gs4d_gather_array* arrays, long long n_src, void* stream);
 
 /* ---- rigidity regulariser building block (with gs4d_knn_query) ----
  * d[i][s] = || x[idx[i][s]] - x[i] ||_2: the reference's torch.norm(vel[idx] - vel[None, :, None], p=2, dim=-1)

@@ -225,3 +225,51 @@ def test_ply_known_answer_bytes(tmp_path):
     open(p3, "wb").write(b"plx\n")
     with pytest.raises(ValueError):
         GM.read_ply(p3)
+
+
+def test_formats_match_the_reference_text(tmp_path):
+    """The PLY vertex layout and the checkpoint tuple against tests/golden/format_golden.json, which
+    tests/golden/make_format_golden.py reads out of the REFERENCE's own source (construct_list_of_attributes executed on
+    the shapes of an SH-degree-3 model; dtype and column order from save_ply; tuple order from capture / restore,
+    scene/gaussian_model.py:88-120,244-256,281-295) -- the format is pinned to the reference text, not to this
+    repository's own known-answer bytes."""
+    import json
+    import os
+    import struct
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "format_golden.json")))
+    m = model(5, seed=3)
+    # property names / order / dtype as the header states them, and the record as the bytes hold it
+    assert m.construct_list_of_attributes() == gold["ply"]["properties"]
+    path = str(tmp_path / "pc.ply")
+    m.save_ply(path)
+    raw = open(path, "rb").read()
+    head, body = raw.split(b"end_header\n", 1)
+    lines = head.decode().splitlines()
+    assert lines[0] == "ply" and lines[1] == "format binary_little_endian 1.0"
+    assert lines[2] == f"element {gold['ply']['element']} 5"
+    want_type = {"f4": "float"}[gold["ply"]["dtype"]]
+    assert [l for l in lines[3:] if l.startswith("property")] == [f"property {want_type} {n}" for n in gold["ply"]["properties"]]
+    n = gold["ply"]["n_properties"]
+    assert len(body) == 5 * n * 4
+    # column order of a record = the reference's np.concatenate tuple (xyz, normals, f_dc, f_rest, opacities, scale, rotation)
+    cols = {"xyz": m._xyz.detach().numpy(), "normals": np.zeros((5, 3), np.float32),
+            "f_dc": m._features_dc.detach().transpose(1, 2).flatten(start_dim=1).numpy(),
+            "f_rest": m._features_rest.detach().transpose(1, 2).flatten(start_dim=1).numpy(),
+            "opacities": m._opacity.detach().numpy(), "scale": m._scaling.detach().numpy(), "rotation": m._rotation.detach().numpy()}
+    want = np.concatenate([cols[c] for c in gold["ply"]["record_columns"]], axis=1).astype("<f4")
+    got = np.frombuffer(body, dtype="<f4").reshape(5, n)
+    np.testing.assert_array_equal(got, want)
+    assert struct.unpack("<f", body[:4])[0] == float(m._xyz[0, 0])
+    # checkpoint tuple: same length, same element at every position
+    ckpt = m.capture()
+    assert len(ckpt) == gold["checkpoint"]["length"]
+    for i, name in enumerate(gold["checkpoint"]["capture"]):
+        if name.endswith("()"):
+            obj = m
+            for part in name[:-2].split("."):
+                obj = getattr(obj, part)
+            ref = obj()
+            assert type(ckpt[i]) is type(ref) and list(ckpt[i].keys()) == list(ref.keys()), name
+        else:
+            ref = getattr(m, name)
+            assert ckpt[i] is ref or ckpt[i] == ref, name

@@ -11,6 +11,8 @@ v_exp_f32; such a flip changes a pixel by up to alpha*T ~ 4e-3) and their count 
 excluded fraction, the largest error ON the excluded pixels and the achieved errors (pytest -rP / -s shows them);
 tests/test_gpu_exact_exp.py shows that the exclusion is only needed because of exp().
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -371,6 +373,35 @@ def test_nan_opacity_is_blended_like_the_reference():
     assert np.isfinite(out[1].cpu().numpy()).all()         # 0.99, not NaN, reaches the image (as in the reference)
 
 
+def test_non_finite_colour_reaches_only_the_pixels_that_blend_it():
+    """the forward blend has a straight-line loop body -- a pixel that skips an entry (alpha < 1/255,
+    power > 0, finished) blends it with weight 0 -- so a +Inf / NaN colour (SH overflow of a diverged model) would turn
+    0 * Inf into NaN on every pixel of the wave's rectangle, where the reference `continue`s (forward.cu:339-347) and
+    leaves those pixels finite.  Colours are staged as finite values (csrc/blend_fwd.hip), so: wherever the oracle's
+    image is finite the HIP image agrees with it to 1e-5, and pixels that do blend the entry are non-finite or huge in
+    both."""
+    a, cam = scene(400, 96, 80, 17, 0.08)
+    colors = np.random.default_rng(3).uniform(0, 1, (400, 3)).astype(np.float32)
+    colors[11] = np.inf
+    colors[57, 1] = np.nan
+    a["opacities"][11] = a["opacities"][57] = np.float32(0.6)
+    R, color, depth, radii, gb, bb, ib = run_c(a, cam, 3, colors=colors)
+    r = run_oracle(a, cam, 3, colors=colors)
+    want, got = r["color"], color.cpu().numpy()
+    fin = np.isfinite(want).all(axis=0) & (r["margin"] > 2e-5)
+    blended = ~np.isfinite(want).all(axis=0)
+    assert r["tiles_touched"][11] > 0 and r["tiles_touched"][57] > 0 and blended.sum() > 20 and fin.sum() > 1000
+    assert np.isfinite(got[:, fin]).all()
+    assert np.abs(got[:, fin] - want[:, fin]).max() <= 1e-5
+    # the Inf entry's tiles hold pixels that skip it: they sit in the same wave rectangles as pixels that blend it
+    ys, xs = np.nonzero(blended)
+    near = np.zeros_like(blended)
+    near[max(ys.min() - 8, 0):ys.max() + 8, max(xs.min() - 8, 0):xs.max() + 8] = True
+    assert (near & fin).sum() > 50
+    bad = ~np.isfinite(got).all(axis=0) | (np.abs(got).max(axis=0) > 1e30)
+    assert bad[blended & (r["margin"] > 2e-5)].all()     # where the reference blends the diverged splat, so does this
+
+
 def test_backward_parity_long_lists_many_segments():
     """Lists of more than a thousand entries on a handful of tiles: the backward walks them in 128-entry segments from the
     forward's checkpoints (csrc/blend_bwd.hip); low opacities keep most pixels alive to the end of their list, so every
@@ -397,6 +428,10 @@ def test_forward_only_flag_changes_no_output():
     R0, c0, d0, r0, g0, b0, i0 = C_.rasterize_gaussians(*args)
     R1, c1, d1, r1, g1, b1, i1 = C_.rasterize_gaussians_forward_only(*args)
     assert R0 == R1 and torch.equal(c0, c1) and torch.equal(d0, d1) and torch.equal(r0, r1)
+    # ... and does not reserve them either (80 of the ~116 bytes per instance of the binning chunk)
+    L = pkg("_cabi").lib()
+    L.gs4d_binning_bytes_forward_only.restype = C.c_size_t
+    assert b1.numel() < 0.5 * b0.numel() and b1.numel() >= int(L.gs4d_binning_bytes_forward_only(C.c_int(R1)))
     v0, v1 = C_.state_view(3000, R0, 96, 80, g0, b0, i0), C_.state_view(3000, R1, 96, 80, g1, b1, i1)
     for k in ("point_list", "ranges", "n_contrib", "final_T"):
         assert torch.equal(v0[k], v1[k]), k

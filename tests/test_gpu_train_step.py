@@ -73,6 +73,32 @@ def test_fused_adamw_matches_torch_adamw():
     got2.step()                                       # CPU-loaded state is moved / re-laid out, not rejected
 
 
+def test_fused_adamw_honours_betas_and_eps_changed_between_steps():
+    """torch.optim.AdamW reads betas / eps from the group on every step; the fused optimizer's cached launch plan must
+    notice such a change (it batches tensors by those values) instead of stepping on with the old ones."""
+    opt_mod = pkg("optim")
+    cpu = [torch.nn.Parameter(p.clone()) for p in _params(3)[:3]]
+    gpu = [torch.nn.Parameter(p.clone().cuda()) for p in _params(3)[:3]]
+    ref = torch.optim.AdamW([{"params": cpu[:2]}, {"params": cpu[2:]}], lr=1e-3, eps=1e-8)
+    got = opt_mod.FusedAdamW([{"params": gpu[:2]}, {"params": gpu[2:]}], lr=1e-3, eps=1e-8)
+    g = torch.Generator().manual_seed(5)
+    for it in range(5):
+        if it == 2:
+            for o in (ref, got):
+                o.param_groups[0]["betas"] = (0.5, 0.9)
+                o.param_groups[1]["eps"] = 1e-3
+        for pc, pg in zip(cpu, gpu):
+            gr = torch.randn(pc.shape, generator=g)
+            pc.grad = gr.clone().contiguous(memory_format=torch.channels_last) if pc.dim() == 4 else gr.clone()
+            pg.grad = pc.grad.cuda()
+        ref.step()
+        got.step()
+    for i, (pc, pg) in enumerate(zip(cpu, gpu)):
+        err = float((pg.detach().cpu() - pc.detach()).abs().max())
+        assert err <= 1e-6 * max(1.0, float(pc.detach().abs().max())), (i, err)
+        assert float(got.state[pg]["step"]) == float(ref.state[pc]["step"]) == 5.0
+
+
 def test_fused_adamw_refuses_cpu_parameters():
     opt_mod = pkg("optim")
     p = torch.nn.Parameter(torch.zeros(4))

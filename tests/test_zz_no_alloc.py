@@ -16,20 +16,27 @@ pytestmark = pytest.mark.gpu
 def _both(pts):
     cabi = pkg("_cabi")
     L = cabi.lib()
+    L.gs4d_debug_alloc_calls.restype = C.c_ulonglong
     P = pts.shape[0]
     x = torch.from_numpy(pts).cuda()
     want = torch.full((P,), -1.0, device="cuda")
     alloc = cabi.TensorAllocator(x.device)
+    calls0 = L.gs4d_debug_alloc_calls()
     rc = L.gs4d_knn_mean_dist2(alloc.callback, alloc.ctx, C.c_int(P), cabi.ptr(x), cabi.ptr(want), cabi.current_stream(x.device))
     alloc.close()
     cabi.check(rc, "gs4d_knn_mean_dist2")
+    assert L.gs4d_debug_alloc_calls() == calls0 + 1             # the counter sees the allocating entry point's request
     got = torch.full((P,), -2.0, device="cuda")
     torch.cuda.synchronize()
     before = torch.cuda.memory_stats()["allocation.all.allocated"]
+    calls1 = L.gs4d_debug_alloc_calls()
+    free_before, _ = torch.cuda.mem_get_info()                  # hipMemGetInfo: a hipMalloc inside the call would show here
     rc = L.gs4d_knn_mean_dist2_static(C.c_int(P), cabi.ptr(x), cabi.ptr(got), cabi.current_stream(x.device))
     cabi.check(rc, "gs4d_knn_mean_dist2_static")
     torch.cuda.synchronize()
     assert torch.cuda.memory_stats()["allocation.all.allocated"] == before     # nothing went through torch's allocator
+    assert L.gs4d_debug_alloc_calls() == calls1                  # the library asked nobody for memory (callbacks, runtime)
+    assert torch.cuda.mem_get_info()[0] == free_before          # and the device's free memory did not move
     return got.cpu().numpy(), want.cpu().numpy()
 
 

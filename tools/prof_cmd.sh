@@ -1,8 +1,8 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/prof_cmd.sh <name> <python script and args...> -> gpurun_out/r2/<name>_kernel_stats.csv
+# usage (GPU box, repo root): tools/prof_cmd.sh <name> <python script and args...> -> gpurun_out/r3/<name>_kernel_stats.csv
 name=$1; shift
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/r2
+out=$root/gpurun_out/r3
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$name
