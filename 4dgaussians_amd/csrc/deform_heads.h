@@ -180,16 +180,28 @@ __global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
         unsigned hid_bits = 0u;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
+#ifdef HF_EXP_NO_ZLOAD
+            const float4 v = make_float4(0.1f * m, -0.2f, 0.3f * i, 0.4f);
+#else
             const float4 v = *reinterpret_cast<const float4*>(z + 8 * m);
+#endif
             hid_bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
             xh[m] = hf_relu4(v);
         }
 #pragma unroll
         for (int m = 0; m < HF_MAX_SEG_BLOCKS; m++)
+#ifdef HF_EXP_NO_ZLOAD
+            if (m < nseg) xs[m] = make_float4(0.1f, 0.2f * m, 0.3f, 0.4f * h);
+#else
             if (m < nseg) xs[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.seg_beg[hd] + 8 * m));
+#endif
 #pragma unroll
         for (int m = 0; m < HF_MAX_TF_BLOCKS; m++)
+#ifdef HF_EXP_NO_ZLOAD
+            if (m < a.tf_blocks) xt[m] = make_float4(0.5f, 0.2f * m, 0.3f, 0.1f * h);
+#else
             if (m < a.tf_blocks) xt[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.oT + 8 * m));
+#endif
         if (hd == 0 && a.store && live) a.hmask[row * 10 + 8 + h] = hid_bits;
 
         f32x16 c0 = {0}, c1 = {0};
@@ -213,11 +225,22 @@ __global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
             const float4 b = sb1[hd * 16 + 2 * m + h];
             const float4 q = hf_quad(m < 4 ? c0 : c1, m & 3);
             const float4 v = make_float4(q.x + b.x, q.y + b.y, q.z + b.z, q.w + b.w);
+#ifndef HF_EXP_NO_H1STORE
             if (a.store && live) *reinterpret_cast<float4*>(h1row + 8 * m) = v;
+#endif
             bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
             xr[m] = hf_relu4(v);
         }
         if (a.store && live) a.hmask[row * 10 + 2 * hd + h] = bits;   // the backward's ReLU mask: 4 bytes instead of 128
+#ifdef HF_EXP_NO_EPILOGUE
+        {
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 8; m++) acc += xr[m].x + xr[m].y + xr[m].z + xr[m].w;
+            if (acc == 123.456f) a.O[row] = acc;           // never true in practice: keeps the layer alive without memory traffic
+            continue;
+        }
+#endif
         if (hd < 3) {
             f32x16 o = {0};
             const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[hd]) + h * 8 + (i & 7);

@@ -185,6 +185,49 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
     return image, screenspace_points, radii > 0, radii, depth
 
 
+def render_batch(cams, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
+                 scaling_modifier: float = 1.0, stage: str = "fine"):
+    """Several views of one step on one GPU -> [(image, screenspace_points, visibility_filter, radii, depth), ...].
+
+    The reference renders the views of a batch one after the other (train.py:169-189), each with its own deformation
+    query; BASELINE.json's multi-GPU configurations put 2-8 views of a step on every rank.  Here the deformation field
+    is queried ONCE for all B views -- B * P rows with a per-row timestamp, which gs4d_deform_forward takes anyway --
+    and so is its backward: the weight-gradient products, the plane-gradient pipeline and every launch of the field
+    run once per step instead of once per view, and autograd adds up the views' parameter gradients in one reduction
+    per tensor.  The rasterizer then runs once per view on its slice of the rows.  Results per view equal render()'s
+    (identical images; gradients up to the order in which the views are summed)."""
+    B = len(cams)
+    if B == 0:
+        return []
+    if "coarse" in stage or deform is None or B == 1:
+        return [render(c, pc, deform, bg_color, scaling_modifier, stage) for c in cams]
+    shs = pc._features if hasattr(pc, "_features") else pc.get_features
+    n, dev = pc._xyz.shape[0], pc._xyz.device
+    cols = [c.time_force_columns(n, dev) if hasattr(c, "time_force_columns") else
+            (torch.full((n, 1), c.time, dtype=torch.float32, device=dev), torch.full((n, 1), c.force, dtype=torch.float32, device=dev))
+            for c in cams]
+    times, forces = torch.cat([t for t, _ in cols], dim=0), torch.cat([f for _, f in cols], dim=0)
+    tile = lambda t: t.expand(B, *t.shape).reshape(B * n, *t.shape[1:])        # B copies of the rows, one kernel
+    m3, sc, rot, op, sh = deform.forward_dynamic(tile(pc._xyz), tile(pc._scaling), tile(pc._rotation), tile(pc._opacity),
+                                                 tile(shs), times, forces, None)
+    sc, rot, op = activate(sc, rot, op)
+    per_view = [t.view(B, n, *t.shape[1:]).unbind(0) for t in (m3, sc, rot, op, sh)]
+    out = []
+    for b, cam in enumerate(cams):
+        screenspace_points = (_shared_zeros(tuple(pc._xyz.shape), dev).detach().requires_grad_(True) if torch.is_grad_enabled()
+                              else torch.empty_like(pc._xyz))
+        settings = GaussianRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width),
+            tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+            scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+            sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+        image, radii, depth = GaussianRasterizer(raster_settings=settings)(
+            means3D=per_view[0][b], means2D=screenspace_points, shs=per_view[4][b], colors_precomp=None,
+            opacities=per_view[3][b], scales=per_view[1][b], rotations=per_view[2][b], cov3D_precomp=None)
+        out.append((image, screenspace_points, radii > 0, radii, depth))
+    return out
+
+
 @torch.no_grad()
 def render_for_image(cam: Camera, pc: GaussianParams, deform, bg_color, scaling_modifier=1.0, stage="fine"):
     return render(cam, pc, deform, bg_color, scaling_modifier, stage, _image_only=True)   # no visibility mask kernel

@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--P", type=int, default=None, help="override the Gaussian count (then the line is not the headline config)")
     ap.add_argument("--views", type=int, default=8,
                     help="distinct (camera, timestamp, target) views each rank cycles through, one per step (train.py:168-189 draws a random view per iteration)")
+    ap.add_argument("--views-per-gpu", type=int, default=1,
+                    help="views every rank renders per step (BASELINE configs C3-C5 put 2-8 on a rank): one deformation query for all of them "
+                         "(renderer.render_batch), one rasterizer pass each; value counts views")
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-pass", action="store_true", help="skip the separate optimizer-inclusive timing loop")
@@ -189,7 +192,23 @@ def main():
     if dp and dp_hooks == "all":
         deform.deformation_net.data_grad_hook = data_hook
 
+    VPG = max(1, args.views_per_gpu)
+
+    def batch_step():
+        vs = [next_view() for _ in range(VPG)]
+        outs = R.render_batch([v.cam for v in vs], pc, deform, bg)
+        loss = F.l1_loss(outs[0][0], vs[0].target)
+        for o, v in zip(outs[1:], vs[1:]):
+            loss = loss + F.l1_loss(o[0], v.target)
+        (loss / (VPG * world)).backward()                 # mean over the global batch of views
+        if dp:
+            bucket.all_reduce()
+        for p in all_params:
+            p.grad = None
+
     def train_step():
+        if VPG > 1:
+            return batch_step()
         v = next_view()
         # render + L1 in one library call per direction (renderer.render_with_l1 -> gs4d_render_forward / _backward)
         loss, *_ = R.render_with_l1(v.cam, pc, deform, bg, v.target, shs_grad_hook=hook)
@@ -237,7 +256,8 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     stats1 = cabi.forward_stats()
-    view_weight = [sum(1 for i in range(args.steps) if i % V == j) / args.steps for j in range(V)]
+    nviews_timed = args.steps * (VPG if args.mode == "train" else 1)
+    view_weight = [sum(1 for i in range(nviews_timed) if i % V == j) / nviews_timed for j in range(V)]
     _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step")
     _dbg(f"timed region done: {dt / args.steps * 1e3:.3f} ms per step")
     L.gs4d_profile_enable(0)
@@ -390,29 +410,33 @@ def main():
         Lv, Cp = len(net.args.multires), int(kc["output_coordinate_dim"])
         gather_bytes = Lv * 6 * 4 * Cp * 4.0 + Lv * Cp * 4.0                         # corner rows gathered + features written
         L2_PEAK_GBS = 34500.0                                                        # MI355X_MICROARCH.md: aggregate L2
+        PD = P * (VPG if args.mode == "train" else 1)                                # rows of one deformation launch
         spec = {  # stage -> (bound, units of work per launch, unit, peak, kernel name prefix in the PMC files, what)
-            "hexplane_forward": ("l2-gather", P * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_forward_kernel",
+            "hexplane_forward": ("l2-gather", PD * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_forward_kernel",
                                  "levels*6*4*C*4 B gathered + L*C*4 B written per Gaussian (SURVEY upper bound: served by L2 / Infinity Cache, the planes themselves are read from HBM once)"),
-            "mlp_forward": ("mfma", P * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_forward_kernel", "2*sum(in*out) FLOP per Gaussian, exact-f32 MFMA"),
+            "mlp_forward": ("mfma", PD * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_forward_kernel", "2*sum(in*out) FLOP per Gaussian, exact-f32 MFMA"),
             "preprocess": ("hbm", 311.0 * P, "GB/s", HBM_PEAK_GBS, "preprocess_kernel", "311 B per Gaussian"),
             "radix_sort": ("hbm", 144.0 * Rn, "GB/s", HBM_PEAK_GBS, "segment_depth_sort_kernel", "24 B per instance and pass x 6 LSD passes (the tile-first sort moves 72 B per instance)"),
             "blend_forward": ("valu", 25.0 * pairs_bwd, "TFLOP/s", FP32_PEAK_TFLOPS, "blend_forward_kernel<false, true>", "25 FLOP per (pixel, Gaussian) pair"),
             "blend_backward": ("valu", 60.0 * pairs_bwd, "TFLOP/s", FP32_PEAK_TFLOPS, "blend_backward_kernel", "60 FLOP per (pixel, Gaussian) pair"),
             "geom_backward": ("hbm", 567.0 * P + 48.0 * Rn, "GB/s", HBM_PEAK_GBS, "geom_backward_kernel", "567 B per Gaussian + 48 B per instance row"),
-            "mlp_backward": ("mfma", P * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_backward_kernel", "input gradients of every Linear: the forward's FLOP count"),
-            "weight_grads": ("mfma", P * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "dw_partial_kernel", "weight gradients of every Linear: the forward's FLOP count"),
-            "hexplane_backward": ("l2-gather", 2.0 * P * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_backward_point_kernel", "twice the forward's gather figure (read the corners, add the gradients)"),
+            "mlp_backward": ("mfma", PD * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_backward_kernel", "input gradients of every Linear: the forward's FLOP count"),
+            "weight_grads": ("mfma", PD * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "dw_partial_kernel", "weight gradients of every Linear: the forward's FLOP count"),
+            "hexplane_backward": ("l2-gather", 2.0 * PD * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_backward_point_kernel", "twice the forward's gather figure (read the corners, add the gradients)"),
         }
-        step_ms = sum(stages.values()) or 1.0
+        DEFORM_STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "activate_backward", "mlp_backward", "hexplane_backward", "weight_grads")
+        launches = lambda st: 1 if (st in DEFORM_STAGES or args.mode != "train") else VPG
+        step_ms = sum(v * launches(k) for k, v in stages.items()) or 1.0
         rooflines = []
         for st, (bound, work, unit, peak, kern, what) in spec.items():
             ms = stages.get(st)
-            if not ms or ms < 0.05 * step_ms:
+            if not ms or ms * launches(st) < 0.05 * step_ms:
                 continue
             ach = work / (ms * 1e-3) / (1e12 if unit == "TFLOP/s" else 1e9)
             traffic, src = pmc_traffic(kern)
             e = {"stage": st, "bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-                 "stage_ms": round(ms, 4), "share_of_step": round(ms / step_ms, 3), "work_per_launch": work, "what": what,
+                 "stage_ms": round(ms, 4), "launches_per_step": launches(st), "share_of_step": round(ms * launches(st) / step_ms, 3),
+                 "work_per_launch": work, "what": what,
                  "dominant_kernel": kern.split("<")[0], "dominant_kernel_traffic": traffic, "traffic_source": src}
             if st in ("radix_sort", "blend_forward", "blend_backward"):
                 e["lds"] = pmc_lds(kern, ms)
@@ -433,13 +457,13 @@ def main():
         unit = "view-iterations/s (fwd+bwd)" if args.mode == "train" else "frames/s"
         metric = "train iters/sec (fwd+bwd)" if args.mode == "train" else "render FPS"
         out = {
-            "metric": metric, "value": round(world * args.steps / dt, 3), "unit": unit, "n_gpus": world,
+            "metric": metric, "value": round(world * nviews_timed / dt, 3), "unit": unit, "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.config}: {W}x{H}, P={P} Gaussians, SH degree 3, "
                                    f"{'mutant' if args.config != 'C5' else 'force_blend'}-shaped HexPlane deformation, "
-                                   f"1 view per GPU per step, {V} distinct (camera, timestamp, target) views cycled",
-                       "global_batch_views": world, "views_cycled": V,
+                                   f"{VPG if args.mode == 'train' else 1} view(s) per GPU per step, {V} distinct (camera, timestamp, target) views cycled",
+                       "global_batch_views": world * (VPG if args.mode == "train" else 1), "views_cycled": V,
                        "parallelism": f"view-dp{world}", "num_rendered": round(Rn, 1), "tiles_per_gaussian": round(Rn / P, 3),
                        "num_rendered_per_view": [r for r, _ in per_view],
                        "log_s0_offset": round(log_s0_offset, 4),

@@ -191,3 +191,35 @@ def test_c2_headline_scene_one_call_equals_staged():
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert_same(params, names, ga, gb)
+
+
+def test_render_batch_equals_per_view_renders():
+    """render_batch: ONE deformation query (B * P rows, per-row timestamps) + B rasterizer passes, against B render()
+    calls: identical images / radii / depth, gradients equal up to the order in which the views are summed."""
+    R, pc, deform, cam, bg, target = small_scene(seed=21)
+    syn, F = pkg("synthetic"), pkg("fused")
+    dev = bg.device
+    cams = [cam] + [R.Camera(syn.look_at_camera(160, 112, azimuth=0.9 + 0.5 * j, elevation=0.2 + 0.1 * j), dev, time=0.1 + 0.27 * j)
+                    for j in range(1, 4)]
+    targets = [torch.rand(3, 112, 160, device=dev, generator=torch.Generator(device=dev).manual_seed(40 + j)) for j in range(4)]
+    names, params = named(pc, deform)
+
+    def one_by_one():
+        outs = [R.render(c, pc, deform, bg) for c in cams]
+        sum(F.l1_loss(o[0], t) for o, t in zip(outs, targets)).backward()
+        return [(o[0].detach().clone(), o[3].clone(), o[4].detach().clone(), o[1].grad.clone()) for o in outs]
+
+    def batched():
+        outs = R.render_batch(cams, pc, deform, bg)
+        sum(F.l1_loss(o[0], t) for o, t in zip(outs, targets)).backward()
+        return [(o[0].detach().clone(), o[3].clone(), o[4].detach().clone(), o[1].grad.clone()) for o in outs]
+
+    a, ga = run(R, False, one_by_one, params)
+    b, gb = run(R, False, batched, params)
+    for va, vb in zip(a, b):
+        for x, y in zip(va, vb):
+            assert torch.equal(x, y)
+    for n, x, y in zip(names, ga, gb):
+        assert (x is None) == (y is None), n
+        if x is not None:
+            assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()) + 1e-12, (n, float((x - y).abs().max()), float(x.abs().max()))
