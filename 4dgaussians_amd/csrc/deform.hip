@@ -1543,6 +1543,7 @@ __global__ __launch_bounds__(256) void ft_embed_final_kernel(int nparts, const f
 }
 
 #include "deform_heads.h"
+#include "deform_heads_bf16.h"
 
 // ---- host side of the fused heads (deform_heads.h)
 static bool heads_layered_forced()
@@ -1581,6 +1582,26 @@ static size_t heads_forward_layout(HeadsArgs& a)
     return (size_t)off * sizeof(float);
 }
 
+// GS4D_MFMA=bf16x3 (environment, read once): the opt-in split-operand kernels of deform_heads_bf16.h; anything else,
+// or nothing, is the exact-f32 default
+static bool mfma_bf16x3()
+{
+    static const bool v = [] { const char* e = getenv("GS4D_MFMA"); return e && (e[0] == 'b' || e[0] == 'B'); }();
+    return v;
+}
+
+// the same regions with every group of K blocks (hidden / segment / embedding) padded to whole K PAIRS
+static size_t heads_forward_layout_bf16(HeadsArgs& a)
+{
+    int off = 0;
+    for (int h = 0; h < NHEAD; h++) { a.w1_off[h] = off; off += (8 + hb_even(a.seg_blocks[h]) + hb_even(a.tf_blocks)) * 8 * WIDTH; }
+    for (int h = 0; h < 3; h++) { a.w2_off[h] = off; off += 8 * 2 * 8 * 4; }
+    a.w2_off[3] = off; off += 8 * 2 * 48 * 4;
+    a.b1_off = off; off += NHEAD * WIDTH;
+    a.b2_off = off; off += 64 + 48;
+    return (size_t)off * sizeof(float);
+}
+
 // backward layout (floats): W2^T of the four heads (1, 1, 1, 6 output blocks of 512) | W1^T hidden parts (4 x 4096) |
 // W1^T segment parts: pos (64 rows), scales (32 rows), rotations (32 rows)
 static size_t heads_backward_layout(HeadsArgs& a)
@@ -1603,6 +1624,7 @@ static bool heads_fused_ok(const gs4d_deform_desc* d, const Layout& l)
         if (a.seg_blocks[h] > HF_MAX_SEG_BLOCKS) return false;
     if (a.tf_blocks > HF_MAX_TF_BLOCKS) return false;
     if (a.seg_len[1] > 32 || a.seg_len[2] > 32) return false;      // backward: one 32-row tile per small segment
+    if (mfma_bf16x3() && heads_forward_layout_bf16(a) > HEADS_LDS_LIMIT) return false;
     return heads_forward_layout(a) <= HEADS_LDS_LIMIT && heads_backward_layout(a) <= HEADS_LDS_LIMIT;
 }
 
@@ -1620,15 +1642,17 @@ static int heads_grid(int nunits)
 
 static int launch_heads_forward(HeadsArgs& a, hipStream_t s)
 {
-    const size_t lds = heads_forward_layout(a);
-    static size_t attr = 0;                      // the largest dynamic LDS size announced so far
-    if (lds > attr) {
-        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)heads_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = lds;
+    const bool split = mfma_bf16x3();
+    const size_t lds = split ? heads_forward_layout_bf16(a) : heads_forward_layout(a);
+    auto kern = split ? heads_forward_bf16x3_kernel : heads_forward_kernel;
+    static size_t attr[2] = {0, 0};              // the largest dynamic LDS size announced so far, per kernel
+    if (lds > attr[split]) {
+        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr[split] = lds;
     }
     const int grid = heads_grid(a.nunits);
     a.nunits = heads_debug_units(a.nunits);
-    hipLaunchKernelGGL(heads_forward_kernel, dim3(grid), dim3(HFF_THREADS), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(HFF_THREADS), lds, s, a);
     GS4D_LAUNCH_CHECK("deform_heads_forward", 0, s);
     return GS4D_OK;
 }

@@ -21,7 +21,9 @@
 #pragma once
 
 #define HF_THREADS 512
+#ifndef HFF_THREADS
 #define HFF_THREADS 768          // forward: 152 VGPRs -> three waves per SIMD
+#endif
 #define HF_WAVES (HF_THREADS / 64)
 #define HF_MAX_SEG_BLOCKS 8
 #define HF_MAX_TF_BLOCKS 4
@@ -112,48 +114,67 @@ __global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
     int* s_next = &s_next_item;
     const int tid = threadIdx.x;
     if (tid == 0) s_next_item = 0;
-    // zero the W1 region (padding columns), then every thread fetches its share of a head's weights in ONE batch of
-    // loads before the first LDS store: staging costs a few memory round trips, not one per element
+    // Weight staging.  EVERY global load of the prologue -- W1 and W2 of the four heads, the biases -- is issued before
+    // the first LDS store, with clamped addresses instead of loads under a condition (one memory round trip instead of
+    // one per head and per W2 loop trip); the padding columns of the W1 region are zeroed while the loads are in flight.
     {
-        const int total4 = (a.w1_off[NHEAD - 1] + (8 + a.seg_blocks[NHEAD - 1] + a.tf_blocks) * 8 * WIDTH) >> 2;
-        float4* z4 = reinterpret_cast<float4*>(smem);
-        for (int e = tid; e < total4; e += HFF_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    for (int hd = 0; hd < NHEAD; hd++) {
-        float* dst = smem + a.w1_off[hd];
-        const float* __restrict__ W = a.W1[hd];
-        const int ld = a.in_w[hd];
-        const int j = min(tid >> 3, WIDTH - 1), c0 = tid & 7;  // row (H1 unit) and first column of this thread (threads >= 512 idle here)
-        const int tf0 = WIDTH + a.seg_len[hd], tfp = WIDTH + a.seg_blocks[hd] * 8;   // first tf column: true / padded
-        float v[(WIDTH + HF_MAX_SEG_BLOCKS * 8 + HF_MAX_TF_BLOCKS * 8) / 8];
+        constexpr int NV = (WIDTH + HF_MAX_SEG_BLOCKS * 8 + HF_MAX_TF_BLOCKS * 8) / 8;      // W1 columns per thread
+        const int j1 = min(tid >> 3, WIDTH - 1), c0 = tid & 7;  // row (H1 unit) and first column of this thread (threads >= 512 idle for W1)
+        float w1v[NHEAD][NV];
 #pragma unroll
-        for (int it = 0; it < (int)(sizeof(v) / sizeof(float)); it++) {
-            const int c = c0 + 8 * it;
-            v[it] = c < ld ? W[(size_t)j * ld + c] : 0.f;
+        for (int hd = 0; hd < NHEAD; hd++) {
+            const float* __restrict__ W = a.W1[hd] + (size_t)j1 * a.in_w[hd];
+            const int last = a.in_w[hd] - 1;
+#pragma unroll
+            for (int it = 0; it < NV; it++) w1v[hd][it] = W[min(c0 + 8 * it, last)];
+        }
+        // W2: pos / scales / rotations as 8 x 64 (rows past the head's outputs are zero), shs as 48 x 64
+        float w2s[3], w2h[(48 * WIDTH + HFF_THREADS - 1) / HFF_THREADS];
+        const int e2 = min(tid, 8 * WIDTH - 1), j2 = e2 >> 6, k2 = e2 & 63;
+#pragma unroll
+        for (int hd = 0; hd < 3; hd++) w2s[hd] = a.W2[hd][(size_t)min(j2, (hd == 2 ? 4 : 3) - 1) * WIDTH + k2];
+#pragma unroll
+        for (int q = 0; q < (int)(sizeof(w2h) / sizeof(float)); q++) w2h[q] = a.W2[3][min(tid + q * HFF_THREADS, 48 * WIDTH - 1)];
+        const float b1v = a.b1[min(tid >> 6, NHEAD - 1)][tid & 63];
+        float b2v = 0.f;
+        {
+            const int e = tid;       // the columns of O: pos 0..2, scales 8..10, rotations 16..19; then the 48 shs outputs at 64..111
+            const int hd = e < OC_S ? 0 : (e < OC_R ? 1 : 2), off = e - (hd == 0 ? OC_X : (hd == 1 ? OC_S : OC_R));
+            const bool small = e < 64 && off >= 0 && off < (hd == 2 ? 4 : 3);
+            const bool big = e >= 64 && e < 64 + 48;
+            const float* src = big ? a.b2[3] + (e - 64) : a.b2[hd] + (small ? off : 0);
+            b2v = *src;
+            if (!small && !big) b2v = 0.f;
+        }
+        {
+            const int total4 = (a.w1_off[NHEAD - 1] + (8 + a.seg_blocks[NHEAD - 1] + a.tf_blocks) * 8 * WIDTH) >> 2;
+            float4* z4 = reinterpret_cast<float4*>(smem);
+            for (int e = tid; e < total4; e += HFF_THREADS) z4[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hd = 0; hd < NHEAD; hd++) {
+            float* dst = smem + a.w1_off[hd];
+            const int ld = a.in_w[hd];
+            const int tf0 = WIDTH + a.seg_len[hd], tfp = WIDTH + a.seg_blocks[hd] * 8;   // first tf column: true / padded
+#pragma unroll
+            for (int it = 0; it < NV; it++) {
+                const int c = c0 + 8 * it;
+                if (c < ld && tid < 8 * WIDTH) dst[hf_slot(c < tf0 ? c : c - tf0 + tfp, j1, WIDTH)] = w1v[hd][it];
+            }
+        }
+        if (tid < 8 * WIDTH) {
+#pragma unroll
+            for (int hd = 0; hd < 3; hd++) smem[a.w2_off[hd] + hf_slot(k2, j2, 8)] = j2 < (hd == 2 ? 4 : 3) ? w2s[hd] : 0.f;
         }
 #pragma unroll
-        for (int it = 0; it < (int)(sizeof(v) / sizeof(float)); it++) {
-            const int c = c0 + 8 * it;
-            if (c < ld && tid < 8 * WIDTH) dst[hf_slot(c < tf0 ? c : c - tf0 + tfp, j, WIDTH)] = v[it];
+        for (int q = 0; q < (int)(sizeof(w2h) / sizeof(float)); q++) {
+            const int e = tid + q * HFF_THREADS;
+            if (e < 48 * WIDTH) smem[a.w2_off[3] + hf_slot(e & 63, e >> 6, 48)] = w2h[q];
         }
-        const int rows = hd == 3 ? 48 : 8, nout = hd == 3 ? 48 : (hd == 2 ? 4 : 3);
-        float* d2 = smem + a.w2_off[hd];
-        const float* __restrict__ W2 = a.W2[hd];
-        for (int e = tid; e < rows * WIDTH; e += HFF_THREADS) {
-            const int j = e >> 6, k = e & 63;
-            d2[hf_slot(k, j, rows)] = j < nout ? W2[(size_t)j * WIDTH + k] : 0.f;
-        }
-        for (int e = tid; e < WIDTH; e += HFF_THREADS) smem[a.b1_off + hd * WIDTH + e] = a.b1[hd][e];
+        if (tid < NHEAD * WIDTH) smem[a.b1_off + tid] = b1v;
+        if (tid < 64 + 48) smem[a.b2_off + tid] = b2v;
     }
-    for (int e = tid; e < 64; e += HFF_THREADS) {
-        float v = 0.f;
-        if (e < 3) v = a.b2[0][e];
-        else if (e >= OC_S && e < OC_S + 3) v = a.b2[1][e - OC_S];
-        else if (e >= OC_R && e < OC_R + 4) v = a.b2[2][e - OC_R];
-        smem[a.b2_off + e] = v;
-    }
-    for (int e = tid; e < 48; e += HFF_THREADS) smem[a.b2_off + 64 + e] = a.b2[3][e];
     __syncthreads();
 
     const int lane = tid & 63, i = lane & 31, h = lane >> 5;
@@ -180,28 +201,16 @@ __global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
         unsigned hid_bits = 0u;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
-#ifdef HF_EXP_NO_ZLOAD
-            const float4 v = make_float4(0.1f * m, -0.2f, 0.3f * i, 0.4f);
-#else
             const float4 v = *reinterpret_cast<const float4*>(z + 8 * m);
-#endif
             hid_bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
             xh[m] = hf_relu4(v);
         }
 #pragma unroll
         for (int m = 0; m < HF_MAX_SEG_BLOCKS; m++)
-#ifdef HF_EXP_NO_ZLOAD
-            if (m < nseg) xs[m] = make_float4(0.1f, 0.2f * m, 0.3f, 0.4f * h);
-#else
             if (m < nseg) xs[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.seg_beg[hd] + 8 * m));
-#endif
 #pragma unroll
         for (int m = 0; m < HF_MAX_TF_BLOCKS; m++)
-#ifdef HF_EXP_NO_ZLOAD
-            if (m < a.tf_blocks) xt[m] = make_float4(0.5f, 0.2f * m, 0.3f, 0.1f * h);
-#else
             if (m < a.tf_blocks) xt[m] = hf_relu4(*reinterpret_cast<const float4*>(z + a.oT + 8 * m));
-#endif
         if (hd == 0 && a.store && live) a.hmask[row * 10 + 8 + h] = hid_bits;
 
         f32x16 c0 = {0}, c1 = {0};
@@ -225,22 +234,11 @@ __global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
             const float4 b = sb1[hd * 16 + 2 * m + h];
             const float4 q = hf_quad(m < 4 ? c0 : c1, m & 3);
             const float4 v = make_float4(q.x + b.x, q.y + b.y, q.z + b.z, q.w + b.w);
-#ifndef HF_EXP_NO_H1STORE
             if (a.store && live) *reinterpret_cast<float4*>(h1row + 8 * m) = v;
-#endif
             bits |= (v.x > 0.f ? 1u : 0u) << (4 * m) | (v.y > 0.f ? 2u : 0u) << (4 * m) | (v.z > 0.f ? 4u : 0u) << (4 * m) | (v.w > 0.f ? 8u : 0u) << (4 * m);
             xr[m] = hf_relu4(v);
         }
         if (a.store && live) a.hmask[row * 10 + 2 * hd + h] = bits;   // the backward's ReLU mask: 4 bytes instead of 128
-#ifdef HF_EXP_NO_EPILOGUE
-        {
-            float acc = 0.f;
-#pragma unroll
-            for (int m = 0; m < 8; m++) acc += xr[m].x + xr[m].y + xr[m].z + xr[m].w;
-            if (acc == 123.456f) a.O[row] = acc;           // never true in practice: keeps the layer alive without memory traffic
-            continue;
-        }
-#endif
         if (hd < 3) {
             f32x16 o = {0};
             const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[hd]) + h * 8 + (i & 7);
@@ -326,27 +324,71 @@ __global__ __launch_bounds__(HF_THREADS) void heads_backward_kernel(HeadsArgs a)
     extern __shared__ float smem[];
     const int tid = threadIdx.x;
 
-    for (int hd = 0; hd < NHEAD; hd++) {
-        const int nout = hd == 3 ? 48 : (hd == 2 ? 4 : 3), ob = hd == 3 ? 6 : 1;
-        float* d2 = smem + a.w2_off[hd];                       // A[i = unit][k = output] = W2[k][i]
-        const float* __restrict__ W2 = a.W2[hd];
-        for (int e = tid; e < ob * 8 * WIDTH; e += HF_THREADS) {
-            const int k = e >> 6, unit = e & 63;
-            d2[hf_slot(k, unit, WIDTH)] = k < nout ? W2[(size_t)k * WIDTH + unit] : 0.f;
+    // Weight staging: every global load of the prologue is issued before the first LDS store, with clamped addresses
+    // instead of loads under a condition (see heads_forward_kernel): one memory round trip instead of ~a dozen.
+    {
+        float w2s[3], w2h[6], w1h[NHEAD][8], sp[8], ss[2][4];
+        const int k8 = tid >> 6, u8 = tid & 63;                     // small heads' W2^T: k = output (0..7), unit
+#pragma unroll
+        for (int hd = 0; hd < 3; hd++) w2s[hd] = a.W2[hd][(size_t)min(k8, (hd == 2 ? 4 : 3) - 1) * WIDTH + u8];
+#pragma unroll
+        for (int q = 0; q < 6; q++) w2h[q] = a.W2[3][tid + q * HF_THREADS];                 // 48 x 64, k = e >> 6, unit = e & 63
+#pragma unroll
+        for (int hd = 0; hd < NHEAD; hd++) {
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int e = tid + q * HF_THREADS;                 // unit = e >> 6, hidden column = e & 63
+                w1h[hd][q] = a.W1[hd][(size_t)(e >> 6) * a.in_w[hd] + (e & 63)];
+            }
         }
-        float* d1 = smem + a.w1_off[hd];                       // A[i = hidden column][k = unit] = W1[unit][i]
-        const float* __restrict__ W = a.W1[hd];
-        const int ld = a.in_w[hd];
-        for (int e = tid; e < WIDTH * WIDTH; e += HF_THREADS) {
-            const int unit = e >> 6, col = e & 63;
-            d1[hf_slot(unit, col, WIDTH)] = W[(size_t)unit * ld + col];
+        {
+            const int lastc = max(a.seg_len[0] - 1, 0);
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int e = tid + q * HF_THREADS;                 // pos segment, 64 rows: unit = e >> 6, column = e & 63
+                sp[q] = a.W1[0][(size_t)(e >> 6) * a.in_w[0] + WIDTH + min(e & 63, lastc)];
+            }
         }
-        if (hd < 3 && a.seg_len[hd] > 0) {                     // A[i = segment column][k = unit] = W1[unit][64 + i]
-            const int rows = hd == 0 ? 64 : 32;
-            float* ds = smem + a.seg_off[hd];
-            for (int e = tid; e < WIDTH * rows; e += HF_THREADS) {
-                const int unit = e / rows, col = e - unit * rows;
-                ds[hf_slot(unit, col, rows)] = col < a.seg_len[hd] ? W[(size_t)unit * ld + WIDTH + col] : 0.f;
+#pragma unroll
+        for (int hd = 1; hd < 3; hd++) {
+            const int lastc = max(a.seg_len[hd] - 1, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = tid + q * HF_THREADS;                 // scales / rotations segment, 32 rows: unit = e >> 5, column = e & 31
+                ss[hd - 1][q] = a.W1[hd][(size_t)(e >> 5) * a.in_w[hd] + WIDTH + min(e & 31, lastc)];
+            }
+        }
+#pragma unroll
+        for (int hd = 0; hd < 3; hd++)                              // A[i = unit][k = output] = W2[k][i]
+            smem[a.w2_off[hd] + hf_slot(k8, u8, WIDTH)] = k8 < (hd == 2 ? 4 : 3) ? w2s[hd] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const int e = tid + q * HF_THREADS;
+            smem[a.w2_off[3] + hf_slot(e >> 6, e & 63, WIDTH)] = w2h[q];
+        }
+#pragma unroll
+        for (int hd = 0; hd < NHEAD; hd++) {                        // A[i = hidden column][k = unit] = W1[unit][i]
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int e = tid + q * HF_THREADS;
+                smem[a.w1_off[hd] + hf_slot(e >> 6, e & 63, WIDTH)] = w1h[hd][q];
+            }
+        }
+        if (a.seg_len[0] > 0) {                                     // A[i = segment column][k = unit] = W1[unit][64 + i]
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int e = tid + q * HF_THREADS;
+                smem[a.seg_off[0] + hf_slot(e >> 6, e & 63, 64)] = (e & 63) < a.seg_len[0] ? sp[q] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int hd = 1; hd < 3; hd++) {
+            if (a.seg_len[hd] > 0) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int e = tid + q * HF_THREADS;
+                    smem[a.seg_off[hd] + hf_slot(e >> 5, e & 31, 32)] = (e & 31) < a.seg_len[hd] ? ss[hd - 1][q] : 0.f;
+                }
             }
         }
     }

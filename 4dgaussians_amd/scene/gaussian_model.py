@@ -193,9 +193,12 @@ def read_ply(path):
 
 
 class GaussianModel:
-    def __init__(self, sh_degree: int, args, device="cuda", optimizer_cls=None):
+    def __init__(self, sh_degree: int, args, device="cuda", optimizer_cls=None, spatial_order: bool = False):
         self.device = torch.device(device)
         self._optimizer_cls = optimizer_cls
+        # spatial_order (no reference counterpart; off: the reference's row order is kept): store the Gaussians in the
+        # Morton order of their positions -- at create_from_pcd and after every densify -- see reorder_spatially()
+        self.spatial_order = bool(spatial_order)
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
         self._xyz = torch.empty(0)
@@ -292,6 +295,8 @@ class GaussianModel:
         self._opacity = leaf(inverse_sigmoid(torch.full((n, 1), 0.1, dtype=torch.float32, device=dev)))
         self.max_radii2D = torch.zeros(n, device=dev)
         self._deformation_table = torch.ones(n, dtype=torch.bool, device=dev)
+        if self.spatial_order:
+            self.reorder_spatially()
 
     # ---- optimizer
     def training_setup(self, training_args):
@@ -537,7 +542,36 @@ class GaussianModel:
         index = torch.cat((self._rows(), picked))
         fresh = torch.cat((torch.zeros(n, dtype=torch.bool, device=dev), torch.ones(picked.numel(), dtype=torch.bool, device=dev)))
         index, fresh, tails = self._split_and_apply(index, fresh, grads, max_grad, extent, 2)
+        if self.spatial_order:
+            index, fresh, tails = self._spatially_sorted(index, fresh, tails)
         self._resample(index, fresh, tails, reset_stats=True)
+
+    @staticmethod
+    def _morton_order(xyz, bits: int = 10):
+        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
+        q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
+        code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
+        for b in range(bits):
+            for axis in range(3):
+                code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
+        return torch.argsort(code, stable=True)
+
+    def _spatially_sorted(self, index, fresh, tails):
+        """Compose a pending edit (index / fresh / tails of _resample) with the Morton order of the rows it produces: the
+        gather then writes the edited model spatially sorted, at no extra pass.  The tail rows (new positions of a split)
+        come after the permutation, so they are folded into ordinary rows first."""
+        xyz = self._xyz.detach()[index]
+        n_tail = 0 if not tails else int(next(iter(tails.values())).shape[0])
+        if n_tail:
+            xyz = xyz.clone()
+            xyz[-n_tail:] = tails["xyz"]
+        order = self._morton_order(xyz)
+        if not n_tail:
+            return index[order], fresh[order], tails
+        # rows that take a tail value cannot move inside one gather: apply the edit first, sort in a second gather
+        self._resample(index, fresh, tails, reset_stats=True)
+        n = self._xyz.shape[0]
+        return order, torch.zeros(n, dtype=torch.bool, device=order.device), None
 
     @torch.no_grad()
     def reorder_spatially(self, bits: int = 10):
@@ -545,14 +579,7 @@ class GaussianModel:
         neighbouring rows are neighbours in space -- the HexPlane gathers and the kNN regularisers then touch nearby plane
         texels / records together.  A pure permutation through the same gather as every other edit:
         parameters, moments and statistics move with their rows; renders are unchanged up to the order of tile-list ties."""
-        xyz = self._xyz.detach()
-        lo, hi = xyz.min(dim=0).values, xyz.max(dim=0).values
-        q = ((xyz - lo) / (hi - lo).clamp_min(1e-12) * ((1 << bits) - 1)).long().clamp_(0, (1 << bits) - 1)
-        code = torch.zeros(xyz.shape[0], dtype=torch.long, device=xyz.device)
-        for b in range(bits):
-            for axis in range(3):
-                code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
-        order = torch.argsort(code, stable=True)
+        order = self._morton_order(self._xyz.detach(), bits)
         self._resample(order)
         return order
 

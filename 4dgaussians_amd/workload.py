@@ -81,11 +81,28 @@ def build_views(name: str, dev, rank: int = 0, n: int = 8):
     return views
 
 
-def build_scene(name: str, dev, P: int | None = None, rank: int = 0, calibrate: bool = True):
+def morton_permutation(xyz: np.ndarray, bits: int = 10) -> np.ndarray:
+    """Row order that sorts the points by the Morton code of their positions (stable): GaussianModel.reorder_spatially
+    on the host."""
+    lo, hi = xyz.min(axis=0), xyz.max(axis=0)
+    q = np.clip(((xyz - lo) / np.maximum(hi - lo, 1e-12) * ((1 << bits) - 1)).astype(np.int64), 0, (1 << bits) - 1)
+    code = np.zeros(xyz.shape[0], dtype=np.int64)
+    for b in range(bits):
+        for axis in range(3):
+            code |= ((q[:, axis] >> b) & 1) << (3 * b + axis)
+    return np.argsort(code, kind="stable")
+
+
+def build_scene(name: str, dev, P: int | None = None, rank: int = 0, calibrate: bool = True, spatial_order: bool = False):
     """-> dict(pc, deform, cam, cam_np, raw, bg, target, log_s0_offset, W, H, P) for a BASELINE.json config: what
     bench.py's rank `rank` renders each step (its own azimuth / timestamp / target image)."""
     cfg = syn.CONFIGS[name]
     _, _, raw = syn.make_workload(name, P=P)
+    if spatial_order:
+        # the same Gaussians stored in the Morton order of their positions (the generator's order is i.i.d., any order is
+        # the same scene): neighbouring rows then read neighbouring HexPlane texels
+        perm = morton_permutation(raw["xyz"])
+        raw = {k: np.ascontiguousarray(v[perm]) for k, v in raw.items()}
     W, H = cfg["W"], cfg["H"]
     torch.manual_seed(syn.seed_for(name))
     pc = GaussianParams(raw, dev)

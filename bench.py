@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--views-per-gpu", type=int, default=1,
                     help="views every rank renders per step (BASELINE configs C3-C5 put 2-8 on a rank): one deformation query for all of them "
                          "(renderer.render_batch), one rasterizer pass each; value counts views")
+    ap.add_argument("--no-spatial-order", action="store_true",
+                    help="keep the generator's i.i.d. row order instead of storing the Gaussians in the Morton order of their positions")
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-pass", action="store_true", help="skip the separate optimizer-inclusive timing loop")
@@ -124,7 +126,7 @@ def main():
 
     # the scene every rank holds (identical seeds -> identical replicas) and this rank's view of it; the parity tests
     # build the same thing through the same function (tests/test_gpu_c2.py)
-    scene = Wl.build_scene(args.config, dev, P=args.P, rank=rank, calibrate=False)
+    scene = Wl.build_scene(args.config, dev, P=args.P, rank=rank, calibrate=False, spatial_order=not args.no_spatial_order)
     pc, deform, cam, cam_np, bg, target = (scene[k] for k in ("pc", "deform", "cam", "cam_np", "bg", "target"))
     P, W, H = scene["P"], scene["W"], scene["H"]
     # the views this rank cycles through (view 0 = the scene's own view: calibration, parity tests, CPU baseline)
@@ -464,6 +466,7 @@ def main():
                                    f"{'mutant' if args.config != 'C5' else 'force_blend'}-shaped HexPlane deformation, "
                                    f"{VPG if args.mode == 'train' else 1} view(s) per GPU per step, {V} distinct (camera, timestamp, target) views cycled",
                        "global_batch_views": world * (VPG if args.mode == "train" else 1), "views_cycled": V,
+                       "row_order": "generator (i.i.d.)" if args.no_spatial_order else "Morton order of the positions (GaussianModel(spatial_order=True) / reorder_spatially)",
                        "parallelism": f"view-dp{world}", "num_rendered": round(Rn, 1), "tiles_per_gaussian": round(Rn / P, 3),
                        "num_rendered_per_view": [r for r, _ in per_view],
                        "log_s0_offset": round(log_s0_offset, 4),

@@ -273,3 +273,38 @@ def test_formats_match_the_reference_text(tmp_path):
         else:
             ref = getattr(m, name)
             assert ckpt[i] is ref or ckpt[i] == ref, name
+
+
+def test_spatial_order_is_a_pure_permutation_of_the_same_edit():
+    """spatial_order=True (no reference counterpart): densify leaves the rows in the Morton order of their positions; the
+    model is the SAME set of rows -- parameters, Adam moments and the deformation table move together -- as the one
+    the reference order produces, and reorder_spatially() alone changes nothing but the order."""
+    def run(spatial):
+        m = model(80, seed=2)
+        m.spatial_order = spatial
+        step(m)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            m._scaling[:] = torch.where(torch.arange(80)[:, None] % 2 == 0, torch.tensor(-1.0), torch.tensor(-6.0))
+        m.percent_dense = 0.05
+        m.xyz_gradient_accum = torch.rand(80, 1, generator=torch.Generator().manual_seed(3))
+        m.denom = torch.ones(80, 1)
+        m._deformation_table = torch.arange(80) % 3 == 0
+        m.densify(0.5, 0.005, 1.0, None)
+        return m
+
+    a, b = run(False), run(True)
+    assert a._xyz.shape == b._xyz.shape and a._xyz.shape[0] > 80
+    key = lambda m: torch.cat([m._xyz.detach(), m._scaling.detach(), m._opacity.detach(), m._features_dc.detach().flatten(1),
+                               m.optimizer.state[m._xyz]["exp_avg"], m.optimizer.state[m._rotation]["exp_avg_sq"],
+                               m._deformation_table[:, None].float()], dim=1)
+    ka, kb = key(a), key(b)
+    sort_rows = lambda k: k[np.lexsort(k.numpy().T[::-1])]
+    assert torch.equal(sort_rows(ka), sort_rows(kb))                       # the same rows ...
+    order = GM.GaussianModel._morton_order(b._xyz.detach())
+    assert torch.equal(order, torch.arange(order.numel()))                 # ... stored in Morton order
+    assert not torch.equal(GM.GaussianModel._morton_order(a._xyz.detach()), torch.arange(order.numel()))
+    before = key(a)
+    perm = a.reorder_spatially()
+    assert torch.equal(key(a), before[perm]) and a.denom.shape == (a._xyz.shape[0], 1)
+    step(a)                                                                # optimizer state still lines up
