@@ -240,14 +240,24 @@ __global__ __launch_bounds__(HFF_THREADS) void heads_forward_kernel(HeadsArgs a)
         }
         if (a.store && live) a.hmask[row * 10 + 2 * hd + h] = bits;   // the backward's ReLU mask: 4 bytes instead of 128
         if (hd < 3) {
-            f32x16 o = {0};
-            const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[hd]) + h * 8 + (i & 7);
+            // The 3- or 4-wide second Linear of the small heads on the vector ALUs: on the matrix instruction it was one
+            // 32-row tile per K block with 3 or 4 live rows -- 32 MFMAs per item -- and the exact-f32 MFMA shares the f32
+            // ALUs with vector instructions (tools/ubench/mfma_valu_overlap.hip), so nothing hides it; here it is 128
+            // FMAs.  Every lane of a half reads the same weight quad (LDS broadcast), the two halves' partial sums
+            // (k = 8m + 4h + q) meet through one cross-half exchange per output.  (Measured: 109 -> 107 us at C2 -- the
+            // kernel is bound by memory latency at three waves per SIMD, not by ALU cycles.)
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4* w2 = reinterpret_cast<const float4*>(smem + a.w2_off[hd]) + h * 8;
 #pragma unroll
             for (int m = 0; m < 8; m++) {
-                float4 wv = w2[m * 16];
-                if (i >= 8) wv = make_float4(0.f, 0.f, 0.f, 0.f);
-                hf_mm1(o, wv, xr[m]);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const float4 wv = w2[m * 16 + c];
+                    o[c] = fmaf(wv.w, xr[m].w, fmaf(wv.z, xr[m].z, fmaf(wv.y, xr[m].y, fmaf(wv.x, xr[m].x, o[c]))));
+                }
             }
+#pragma unroll
+            for (int c = 0; c < 4; c++) o[c] += __shfl_xor(o[c], 32, 64);
             if (h == 0 && live) {       // features 0..3 of the point sit in registers 0..3 of the h = 0 lane
                 if (hd == 0) {
 #pragma unroll
