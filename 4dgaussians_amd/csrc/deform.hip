@@ -2173,9 +2173,10 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
         }
         // batches of HB points (one batch unless the scene is large, see hex_batch_points): the sorted records and
         // gsix carry batch-local point indices, the plane gradients accumulate over the batches
-        const bool one_batch = HB >= (size_t)P;
-        const bool reuse_order = one_batch && g->hex_order && g->hex_order_valid;
-        int* record_order = (one_batch && g->hex_order && !g->hex_order_valid) ? g->hex_order : nullptr;
+        // the caller's cached order holds one [L][HEX_SORTS][n] block of batch-local indices per batch, batch after batch
+        // (the batch size follows from the descriptor and P alone, so a recorded order and a later pass agree on it)
+        const bool reuse_order = g->hex_order && g->hex_order_valid;
+        const bool record = g->hex_order && !g->hex_order_valid;
         for (size_t p0 = 0; p0 < (size_t)P; p0 += HB) {
             const int n = (int)(((size_t)P - p0) < HB ? ((size_t)P - p0) : HB);
             if (p0 > 0) GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, s));     // the first batch's zeros come from pe_backward
@@ -2188,11 +2189,11 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
             if (reuse_order) {
                 const size_t ne = (size_t)d->L * HEX_SORTS * n;
                 hipLaunchKernelGGL(hexplane_rec_from_order_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, n, d->L,
-                                   d->aabb, pts_b, tp_b, g->hex_order, rec);
+                                   d->aabb, pts_b, tp_b, g->hex_order + (size_t)d->L * HEX_SORTS * p0, rec);
             } else {
                 hipLaunchKernelGGL(hexplane_bin_scan_kernel, dim3(HEX_SORTS * d->L), dim3(1024), 0, s, B.nbins, hist);
                 hipLaunchKernelGGL(hexplane_bin_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, n, d->L, B.nbins, d->aabb,
-                                   pts_b, tp_b, hist, rank, key, rec, record_order);
+                                   pts_b, tp_b, hist, rank, key, rec, record ? g->hex_order + (size_t)d->L * HEX_SORTS * p0 : nullptr);
             }
             hipLaunchKernelGGL(kern, dim3((unsigned)(((size_t)n + per_wg - 1) / per_wg), 6 * d->L), dim3(256), lds, s, n, d->C,
                                d->L, T, rec, gsix);

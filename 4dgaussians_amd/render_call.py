@@ -173,13 +173,14 @@ class _RenderFunction(torch.autograd.Function):
         g.dL_dmeans2D, g.d_xyz, g.d_log_scales, g.d_rotations = d_m2d.data_ptr(), d_xyz.data_ptr(), d_sc.data_ptr(), d_rot.data_ptr()
         g.d_opacity_logit, g.d_shs = d_op.data_ptr(), d_shs.data_ptr()
         param_grads = ()
+        order_key = None
         stage_fn = _NO_STAGE_FN
         if call.deform_net is not None:
             plan, cfg = call.cfg["plan"], call.cfg
             dg, views = plan.new_grads(dev)
             oc = cfg.get("hex_order_cache")
             if oc is not None:
-                oc.bind(dg, P, int(plan.desc.L), dev)
+                order_key = oc.bind(dg, P, int(plan.desc.L), dev)
             else:
                 dg.hex_order, dg.hex_order_valid = None, 0
             g.deform = C.pointer(dg)
@@ -209,6 +210,8 @@ class _RenderFunction(torch.autograd.Function):
                                         C.byref(g), stage_fn, None, _cabi.current_stream(dev))
         scratch.close()
         _cabi.check(rc, "gs4d_render_backward")
+        if order_key is not None:
+            call.cfg["hex_order_cache"].recorded(order_key)
         if stage_fn is not _NO_STAGE_FN and failure:
             raise failure[0]
         return (None, d_xyz, d_sc, d_rot, d_op, d_shs, d_m2d) + param_grads

@@ -73,12 +73,21 @@ class HexOrderCache:
             # order decides only how well adds are combined, a non-permutation would drop or double gradients
             e = self.entries[key] = [torch.arange(P, dtype=torch.int32, device=dev).repeat(L * 3), self.refresh]
         valid = e[1] < self.refresh
-        e[1] = e[1] + 1 if valid else 1
         if valid:
+            e[1] += 1
             self.reuses += 1
         else:
+            # stays stale until the recording pass has returned without an error (recorded()): a scene that runs in
+            # several batches keeps batch-local indices here, which the identity above is not
+            e[1] = self.refresh
             self.records += 1
         g.hex_order, g.hex_order_valid = e[0].data_ptr(), int(valid)
+        return None if valid else key
+
+    def recorded(self, key):
+        """The backward that bind() asked to record the order (key = bind's return value) has been issued."""
+        if key is not None and key in self.entries:
+            self.entries[key][1] = 1
 
 
 def _lib():
@@ -272,8 +281,9 @@ class _DeformFunction(torch.autograd.Function):
                               dtype=torch.uint8, device=dev)
         hook = cfg.get("data_grad_hook")
         order_cache = cfg.get("hex_order_cache")
+        order_key = None
         if order_cache is not None:
-            order_cache.bind(g, P, int(d.L), dev)
+            order_key = order_cache.bind(g, P, int(d.L), dev)
         else:
             g.hex_order, g.hex_order_valid = None, 0
 
@@ -294,6 +304,8 @@ class _DeformFunction(torch.autograd.Function):
             run(BWD_DATA)
             hook(d_xyz, d_sc, d_rot, gp, g_ftw, g_ftb)
             run(BWD_WEIGHTS)
+        if order_cache is not None:
+            order_cache.recorded(order_key)
         param_grads = list(gp) + [None, g_ftw, g_ftb] + list(gt) + list(gh)
         return (d_xyz, d_sc, d_rot, d_shs, None, None, None, *param_grads)
 

@@ -285,8 +285,10 @@ typedef struct gs4d_deform_grads {
      * on that order -- and the points of a scene move little from one iteration to the next.  hex_order: device
      * [L * 3 * P] ints owned by the caller.  hex_order_valid = 0: the backward sorts as usual and leaves the order here;
      * 1: it skips the ranking atomics, the bin scan and the scatter and walks the points in the cached order (same P
-     * and L as when it was recorded; a stale order only groups a little less well).  Ignored when the scene is large
-     * enough for the pipeline to run in several batches. */
+     * and L as when it was recorded; a stale order only groups a little less well).  A scene large enough for the
+     * pipeline to run in several batches (GS4D_HEX_BATCH_BYTES) keeps one [L * 3 * n] block of batch-local indices
+     * per batch, batch after batch: same total size; the environment variable must not change between the recording
+     * call and the calls that reuse the order. */
     int* hex_order;
     int hex_order_valid;
     int reserved_;

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import conftest  # noqa: F401  (puts the repository root on sys.path)
 
 
-def run(P=20000):
+def run(P=20000, second_pass=False):
     from conftest import pkg
     from oracle import deformation_ref as R
     from test_gpu_deformation import make_args
@@ -25,12 +25,23 @@ def run(P=20000):
     # per-point timestamps: the time planes' cells differ from point to point as well
     tm, fc = torch.rand(P, 1, generator=g).cuda(), torch.zeros(P, 1).cuda()
     ws = [torch.randn(s, generator=g).cuda() for s in ((P, 3), (P, 3), (P, 4), (P, 1), (P, 16, 3))]
-    out = net.forward_dynamic(*x, tm, fc, None)
-    sum((o * w).sum() for o, w in zip(out, ws)).backward()
-    res = {"in%d" % i: t.grad.cpu().numpy() for i, t in enumerate(x) if t.grad is not None}
-    res.update({k: p.grad.cpu().numpy() for k, p in net.named_parameters() if p.grad is not None})
+    def grads():
+        for t in list(net.parameters()) + x:
+            t.grad = None
+        out = net.forward_dynamic(*x, tm, fc, None)
+        sum((o * w).sum() for o, w in zip(out, ws)).backward()
+        res = {"in%d" % i: t.grad.cpu().numpy() for i, t in enumerate(x) if t.grad is not None}
+        res.update({k: p.grad.cpu().numpy() for k, p in net.named_parameters() if p.grad is not None})
+        return res
+
+    res = grads()                                   # ranks the points and records the order (batch by batch)
+    if second_pass:
+        again = grads()                             # walks the recorded order
+        cache = net.deformation_net.__dict__["_hex_order_cache"]
+        res.update({"reuse/" + k: v for k, v in again.items()})
+        res["cache_counts"] = np.array([cache.records, cache.reuses])
     return res
 
 
 if __name__ == "__main__":
-    np.savez(sys.argv[1], **run())
+    np.savez(sys.argv[1], **run(second_pass=True))

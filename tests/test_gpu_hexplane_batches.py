@@ -2,7 +2,8 @@
 by cell -> reduce in cell order) runs over BATCHES of points so that its scratch stays bounded (2 GiB by default; a
 5 M-point, 128-channel scene needed 31 GB before).  (a) A child process with GS4D_HEX_BATCH_BYTES = 3 MB (10 batches of
 2 048 points) must produce the gradients of the single-batch run of this process: everything but the plane gradients
-bit for bit (batching only regroups the float atomics of the planes), the planes to 1e-5 of their max.  (b) The
+bit for bit (batching only regroups the float atomics of the planes), the planes to 1e-5 of their max -- on its first
+pass, which ranks the points, and on a second one that walks the order the first recorded (one block per batch).  (b) The
 force_blend-shaped field (C5's network: 128 channels, depth-5 trunk) on 1.2 M points with batches forced down to 256 MB
 (5 batches): size-independent properties -- the scratch the library asks for is bounded, gradients are finite,
 reproducible to float-atomic noise, and LINEAR in the upstream gradient."""
@@ -28,15 +29,18 @@ def test_small_batches_reproduce_single_batch_gradients(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(HERE, "hex_batch_child.py"), out], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     got = np.load(out)
-    assert set(got.files) == set(want)
+    assert set(got.files) == set(want) | {"reuse/" + k for k in want} | {"cache_counts"}
+    # the child's second pass walked the point order its first pass recorded, batch by batch
+    assert got["cache_counts"].tolist() == [1, 1]
     worst = 0.0
-    for k, w in want.items():
-        if "grids" in k:                                   # plane gradients: float atomics, regrouped by the batches
-            err = float(np.abs(got[k] - w).max() / max(np.abs(w).max(), 1e-30))
-            worst = max(worst, err)
-            assert err <= 1e-5, (k, err)
-        else:
-            np.testing.assert_array_equal(got[k], w, err_msg=k)
+    for prefix in ("", "reuse/"):
+        for k, w in want.items():
+            if "grids" in k:                               # plane gradients: float atomics, regrouped by the batches
+                err = float(np.abs(got[prefix + k] - w).max() / max(np.abs(w).max(), 1e-30))
+                worst = max(worst, err)
+                assert err <= 1e-5, (prefix + k, err)
+            else:
+                np.testing.assert_array_equal(got[prefix + k], w, err_msg=prefix + k)
     assert any("grids" in k for k in want)
     print("plane gradients, 10 batches vs 1: max rel err", worst)
 
