@@ -94,34 +94,104 @@ def _fill_desc(d: RenderDesc, call: RenderCall, P, M, xyz, scaling, rotation, op
     d.target = call.target.data_ptr() if call.target is not None else None
 
 
+def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, needs_grad: bool):
+    """gs4d_render_forward -> (color, radii, depth, loss or None, descriptor, state, arena)."""
+    L = _cabi.lib()
+    dev = xyz.device
+    P, M = xyz.shape[0], features.shape[1]
+    flags = (1 if call.debug else 0) | (0 if needs_grad else FORWARD_ONLY)
+    d = RenderDesc()
+    if call.deform_net is not None:
+        call.cfg["plan"].desc.no_grad = 0 if needs_grad else 1
+    _fill_desc(d, call, P, M, xyz, scaling, rotation, opacity, features, flags)
+    color = torch.empty((3, call.H, call.W), dtype=torch.float32, device=dev)
+    depth = torch.empty((1, call.H, call.W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev) if call.target is not None else None
+    state = RenderState()
+    arena = _cabi.ArenaAllocator(dev)
+    with torch.cuda.device(dev):
+        rc = L.gs4d_render_forward(C.byref(d), arena.callback, arena.ctx, C.c_void_p(color.data_ptr()),
+                                   C.c_void_p(depth.data_ptr()), C.c_void_p(radii.data_ptr()),
+                                   C.c_void_p(loss.data_ptr()) if loss is not None else None, C.byref(state),
+                                   _cabi.current_stream(dev))
+    arena.close()
+    _cabi.check(rc, "gs4d_render_forward")
+    return color, radii, depth, loss, d, state, arena
+
+
+class _BackwardBuffers:
+    """Everything gs4d_render_backward writes, allocated BEFORE the forward call is issued when the caller knows that a
+    backward will follow (render_step): the host then has nothing to do between the two library calls."""
+    __slots__ = ("d_xyz", "d_sc", "d_rot", "d_op", "d_shs", "d_m2d", "g", "dg", "views", "order_key")
+
+    def __init__(self, call: RenderCall, dev, P, M, opacity_shape):
+        self.d_xyz, self.d_sc, self.d_rot, self.d_op, self.d_shs = _cabi.empty_group(dev, (P, 3), (P, 3), (P, 4), tuple(opacity_shape),
+                                                                                    (P, M, 3))
+        self.d_m2d = torch.empty((P, 3), dtype=torch.float32, device=dev)
+        g = self.g = RenderGrads()
+        g.dL_dmeans2D, g.d_xyz, g.d_log_scales, g.d_rotations = (self.d_m2d.data_ptr(), self.d_xyz.data_ptr(), self.d_sc.data_ptr(),
+                                                                 self.d_rot.data_ptr())
+        g.d_opacity_logit, g.d_shs = self.d_op.data_ptr(), self.d_shs.data_ptr()
+        self.dg, self.views, self.order_key = None, (), None
+        if call.deform_net is not None:
+            plan, cfg = call.cfg["plan"], call.cfg
+            self.dg, self.views = plan.new_grads(dev)
+            oc = cfg.get("hex_order_cache")
+            if oc is not None:
+                self.order_key = oc.bind(self.dg, P, int(plan.desc.L), dev)
+            else:
+                self.dg.hex_order, self.dg.hex_order_valid = None, 0
+            g.deform = C.pointer(self.dg)
+
+    def param_grads(self, call: RenderCall):
+        if call.deform_net is None:
+            return ()
+        n_pl = call.cfg["plan"].n_planes
+        return tuple(self.views[:n_pl]) + (None,) + tuple(self.views[n_pl:])
+
+
+def _issue_backward(call: RenderCall, d: RenderDesc, state: RenderState, color, radii, g_color, g_depth, g_loss, buf: _BackwardBuffers):
+    """gs4d_render_backward into `buf` (the data-parallel hooks of the call fire from inside it)."""
+    L = _cabi.lib()
+    dev = color.device
+    stage_fn = _NO_STAGE_FN
+    data_hook = call.cfg.get("data_grad_hook") if call.deform_net is not None else None
+    if call.shs_grad_hook is not None or data_hook is not None:
+        failure = []
+
+        def on_stage(_ctx, stage):
+            try:                                   # never let an exception cross the C boundary
+                if stage == STAGE_RASTER_DONE and call.shs_grad_hook is not None:
+                    call.shs_grad_hook(buf.d_shs)
+                elif stage == STAGE_DATA_DONE and data_hook is not None:
+                    n_pl = call.cfg["plan"].n_planes
+                    data_hook(buf.d_xyz, buf.d_sc, buf.d_rot, list(buf.views[:n_pl]), buf.views[n_pl], buf.views[n_pl + 1])
+            except Exception as ex:
+                failure.append(ex)
+
+        stage_fn = STAGE_FN(on_stage)
+    scratch = _cabi.ArenaAllocator(dev)
+    with torch.cuda.device(dev):
+        rc = L.gs4d_render_backward(C.byref(d), C.byref(state), C.c_void_p(color.data_ptr()), C.c_void_p(radii.data_ptr()),
+                                    _cabi.ptr(g_color), _cabi.ptr(g_depth), _cabi.ptr(g_loss), scratch.callback, scratch.ctx,
+                                    C.byref(buf.g), stage_fn, None, _cabi.current_stream(dev))
+    scratch.close()
+    _cabi.check(rc, "gs4d_render_backward")
+    if buf.order_key is not None:
+        call.cfg["hex_order_cache"].recorded(buf.order_key)
+    if stage_fn is not _NO_STAGE_FN and failure:
+        raise failure[0]
+
+
 class _RenderFunction(torch.autograd.Function):
     """(call, xyz, log_scales, rotations, opacity_logit, shs, means2D, *deformation parameters) ->
     (color [3,H,W], radii [P], depth [1,H,W], loss or None)."""
 
     @staticmethod
     def forward(ctx, call, xyz, scaling, rotation, opacity, features, means2D, *params):
-        L = _cabi.lib()
-        dev = xyz.device
-        P, M = xyz.shape[0], features.shape[1]
         needs_grad = any(ctx.needs_input_grad)
-        flags = (1 if call.debug else 0) | (0 if needs_grad else FORWARD_ONLY)
-        d = RenderDesc()
-        if call.deform_net is not None:
-            call.cfg["plan"].desc.no_grad = 0 if needs_grad else 1
-        _fill_desc(d, call, P, M, xyz, scaling, rotation, opacity, features, flags)
-        color = torch.empty((3, call.H, call.W), dtype=torch.float32, device=dev)
-        depth = torch.empty((1, call.H, call.W), dtype=torch.float32, device=dev)
-        radii = torch.empty((P,), dtype=torch.int32, device=dev)
-        loss = torch.empty((), dtype=torch.float32, device=dev) if call.target is not None else None
-        state = RenderState()
-        arena = _cabi.ArenaAllocator(dev)
-        with torch.cuda.device(dev):
-            rc = L.gs4d_render_forward(C.byref(d), arena.callback, arena.ctx, C.c_void_p(color.data_ptr()),
-                                       C.c_void_p(depth.data_ptr()), C.c_void_p(radii.data_ptr()),
-                                       C.c_void_p(loss.data_ptr()) if loss is not None else None, C.byref(state),
-                                       _cabi.current_stream(dev))
-        arena.close()
-        _cabi.check(rc, "gs4d_render_forward")
+        color, radii, depth, loss, d, state, arena = _issue_forward(call, xyz, scaling, rotation, opacity, features, needs_grad)
         ctx.num_rendered = state.num_rendered
         if needs_grad:
             ctx.call, ctx.desc, ctx.state = call, d, state
@@ -167,54 +237,52 @@ class _RenderFunction(torch.autograd.Function):
             keep.append(t)
             return t
         g_color, g_depth, g_loss = f32c(g_color), f32c(g_depth), f32c(g_loss)
-        d_xyz, d_sc, d_rot, d_op, d_shs = _cabi.empty_group(dev, (P, 3), (P, 3), (P, 4), tuple(opacity.shape), (P, M, 3))
-        d_m2d = torch.empty((P, 3), dtype=torch.float32, device=dev)
-        g = RenderGrads()
-        g.dL_dmeans2D, g.d_xyz, g.d_log_scales, g.d_rotations = d_m2d.data_ptr(), d_xyz.data_ptr(), d_sc.data_ptr(), d_rot.data_ptr()
-        g.d_opacity_logit, g.d_shs = d_op.data_ptr(), d_shs.data_ptr()
-        param_grads = ()
-        order_key = None
-        stage_fn = _NO_STAGE_FN
-        if call.deform_net is not None:
-            plan, cfg = call.cfg["plan"], call.cfg
-            dg, views = plan.new_grads(dev)
-            oc = cfg.get("hex_order_cache")
-            if oc is not None:
-                order_key = oc.bind(dg, P, int(plan.desc.L), dev)
+        buf = _BackwardBuffers(call, dev, P, M, opacity.shape)
+        _issue_backward(call, d, state, color, radii, g_color, g_depth, g_loss, buf)
+        return (None, buf.d_xyz, buf.d_sc, buf.d_rot, buf.d_op, buf.d_shs, buf.d_m2d) + buf.param_grads(call)
+
+
+_SCALARS = {}
+
+
+def _device_scalar(dev, value: float):
+    key = (dev.index, float(value))
+    t = _SCALARS.get(key)
+    if t is None:
+        if len(_SCALARS) > 64:
+            _SCALARS.clear()
+        t = _SCALARS[key] = torch.full((), float(value), dtype=torch.float32, device=dev)
+    return t
+
+
+def render_step(call: RenderCall, xyz, scaling, rotation, opacity, features, means2D, loss_scale: float = 1.0):
+    """Forward, fused L1 and backward of one view issued back to back, without an autograd graph in between:
+    d(loss_scale * L1) is ACCUMULATED into .grad of every tensor that requires it (the five Gaussian parameter tensors,
+    means2D, the deformation parameters), exactly what `(loss_scale * loss).backward()` leaves there after
+    render_call() -- same two library calls, same kernels, bit-identical gradients (tests/test_gpu_render_call.py).
+
+    Why it exists: the forward call returns right after the host has read num_rendered, with ~0.2 ms of device work
+    (binning, blend, loss) queued; autograd needs 0.15-0.3 ms of host time between that return and the backward call's
+    first launch, so the GPU idles for 20-90 us per step at C2 (rocprofv3 kernel trace).  Here the
+    gradient buffers exist before the forward call and the backward call follows it directly.
+    -> (color, radii, depth, loss); all detached, loss is the plain (unscaled) L1."""
+    assert call.target is not None
+    dev = xyz.device
+    P, M = xyz.shape[0], features.shape[1]
+    with torch.no_grad():
+        buf = _BackwardBuffers(call, dev, P, M, opacity.shape)
+        g_loss = _device_scalar(dev, loss_scale)
+        color, radii, depth, loss, d, state, arena = _issue_forward(call, xyz, scaling, rotation, opacity, features, True)
+        _issue_backward(call, d, state, color, radii, None, None, g_loss, buf)
+        grads = (buf.d_xyz, buf.d_sc, buf.d_rot, buf.d_op, buf.d_shs, buf.d_m2d) + buf.param_grads(call)
+        for p, g in zip((xyz, scaling, rotation, opacity, features, means2D) + tuple(call.params), grads):
+            if g is None or not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = g.view(p.shape) if g.shape != p.shape else g
             else:
-                dg.hex_order, dg.hex_order_valid = None, 0
-            g.deform = C.pointer(dg)
-            n_pl = plan.n_planes
-            param_grads = tuple(views[:n_pl]) + (None,) + tuple(views[n_pl:])
-            data_hook = cfg.get("data_grad_hook")
-        else:
-            data_hook = None
-        if call.shs_grad_hook is not None or data_hook is not None:
-            failure = []
-
-            def on_stage(_ctx, stage):
-                try:                                   # never let an exception cross the C boundary
-                    if stage == STAGE_RASTER_DONE and call.shs_grad_hook is not None:
-                        call.shs_grad_hook(d_shs)
-                    elif stage == STAGE_DATA_DONE and data_hook is not None:
-                        n_pl = call.cfg["plan"].n_planes
-                        data_hook(d_xyz, d_sc, d_rot, list(views[:n_pl]), views[n_pl], views[n_pl + 1])
-                except Exception as ex:
-                    failure.append(ex)
-
-            stage_fn = STAGE_FN(on_stage)
-        scratch = _cabi.ArenaAllocator(dev)
-        with torch.cuda.device(dev):
-            rc = L.gs4d_render_backward(C.byref(d), C.byref(state), C.c_void_p(color.data_ptr()), C.c_void_p(radii.data_ptr()),
-                                        _cabi.ptr(g_color), _cabi.ptr(g_depth), _cabi.ptr(g_loss), scratch.callback, scratch.ctx,
-                                        C.byref(g), stage_fn, None, _cabi.current_stream(dev))
-        scratch.close()
-        _cabi.check(rc, "gs4d_render_backward")
-        if order_key is not None:
-            call.cfg["hex_order_cache"].recorded(order_key)
-        if stage_fn is not _NO_STAGE_FN and failure:
-            raise failure[0]
-        return (None, d_xyz, d_sc, d_rot, d_op, d_shs, d_m2d) + param_grads
+                p.grad.add_(g.view(p.shape))
+    return color, radii, depth, loss
 
 
 def render_call(call: RenderCall, xyz, scaling, rotation, opacity, features, means2D):

@@ -19,7 +19,7 @@ import torch.nn as nn
 
 from .diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer, _shared_zeros
 from .fused import activate
-from .render_call import RenderCall, render_call
+from .render_call import RenderCall, render_call, render_step
 
 
 class GaussianParams(nn.Module):
@@ -65,7 +65,8 @@ MAX_FRAME = 25                                   # scene/dataset_readers.py:30: 
 STAGED_ONLY = bool(os.environ.get("GS4D_RENDER_STAGED"))      # tests / experiments: never take the one-call path
 
 
-def _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, l1_target):
+def _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, l1_target,
+              step_scale=None):
     """The whole view through gs4d_render_forward (render_call.py) -> (image, radii, depth, loss), or None when the
     one-call path does not apply (non-float32 / non-contiguous / CPU tensors, an empty scene, a deformation module
     without a cached plan): the caller then takes the staged path, which also owns every error message."""
@@ -87,6 +88,8 @@ def _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook,
         return None                       # unsupported deformation configuration: the staged path raises it
     if not call.applicable((xyz, scaling, rotation, opacity, shs)):
         return None
+    if step_scale is not None:
+        return render_step(call, xyz, scaling, rotation, opacity, shs, screenspace_points, step_scale)
     return render_call(call, xyz, scaling, rotation, opacity, shs, screenspace_points)
 
 
@@ -104,6 +107,30 @@ def render_with_l1(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module],
     image, screenspace_points, vis, radii, depth = render(cam, pc, deform, bg_color, scaling_modifier, stage,
                                                           shs_grad_hook=shs_grad_hook)
     return l1_loss(image, target), image, screenspace_points, vis, radii, depth
+
+
+def render_l1_step(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
+                   target: torch.Tensor, loss_scale: float = 1.0, scaling_modifier: float = 1.0, stage: str = "fine",
+                   shs_grad_hook=None):
+    """render_with_l1() AND the backward pass of loss_scale * loss in one go: what the reference's iteration does with
+    `render(...)`, `l1_loss(image, gt)` and `loss.backward()` (train.py:190-203,230) when the L1 term is the image's only
+    consumer.  The gradients are accumulated into `.grad` of the Gaussian parameters, the deformation parameters and the
+    returned screenspace_points; further loss terms (regularisers) run their own backward and accumulate as usual.
+    Forward and backward are issued back to back (render_call.render_step): the host has no autograd work between the
+    two library calls, which is where the GPU idled 20-90 us per step.
+    -> (loss, image, screenspace_points, visibility_filter, radii, depth), all detached; loss is the unscaled L1."""
+    if not STAGED_ONLY:
+        screenspace_points = _shared_zeros(tuple(pc._xyz.shape), pc._xyz.device).detach().requires_grad_(True)
+        out = _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, target,
+                        step_scale=float(loss_scale))
+        if out is not None:
+            image, radii, depth, loss = out
+            return loss, image, screenspace_points, radii > 0, radii, depth
+    with torch.enable_grad():
+        loss, image, screenspace_points, vis, radii, depth = render_with_l1(cam, pc, deform, bg_color, target,
+                                                                            scaling_modifier, stage, shs_grad_hook)
+        (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+    return loss.detach(), image.detach(), screenspace_points, vis, radii, depth
 
 
 def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,

@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--no-spatial-order", action="store_true",
                     help="keep the generator's i.i.d. row order instead of storing the Gaussians in the Morton order of their positions")
     ap.add_argument("--mode", default="train", choices=["train", "fps"])
+    ap.add_argument("--autograd-step", action="store_true",
+                    help="train step as render_with_l1(...) + loss.backward() instead of renderer.render_l1_step "
+                         "(same library calls and gradients; the host then has autograd work between them)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer-pass", action="store_true", help="skip the separate optimizer-inclusive timing loop")
     ap.add_argument("--no-fps-pass", action="store_true", help="(train mode) skip the render-FPS loop that fills `render_fps`")
@@ -195,6 +198,7 @@ def main():
         deform.deformation_net.data_grad_hook = data_hook
 
     VPG = max(1, args.views_per_gpu)
+    FUSED_STEP = not args.autograd_step and not R.STAGED_ONLY
 
     def batch_step():
         vs = [next_view() for _ in range(VPG)]
@@ -213,10 +217,15 @@ def main():
             return batch_step()
         v = next_view()
         # render + L1 in one library call per direction (renderer.render_with_l1 -> gs4d_render_forward / _backward)
-        loss, *_ = R.render_with_l1(v.cam, pc, deform, bg, v.target, shs_grad_hook=hook)
-        if dp:
-            loss = loss / world                           # SUM over ranks == mean over the global batch
-        loss.backward()
+        if FUSED_STEP:
+            # forward + L1 + backward issued back to back, gradients straight into .grad (renderer.render_l1_step);
+            # the SUM over ranks of (1 / world) * loss is the mean over the global batch
+            R.render_l1_step(v.cam, pc, deform, bg, v.target, loss_scale=1.0 / world if dp else 1.0, shs_grad_hook=hook)
+        else:
+            loss, *_ = R.render_with_l1(v.cam, pc, deform, bg, v.target, shs_grad_hook=hook)
+            if dp:
+                loss = loss / world                           # SUM over ranks == mean over the global batch
+            loss.backward()
         if dp:
             bucket.all_reduce()
         for p in all_params:
@@ -477,7 +486,10 @@ def main():
                        # chunk (previous view's R + 1/8) was too small, plane-gradient point orders ranked / reused
                        "timed_region": {"copy_sync_fallback": stats1[1] - stats0[1], "binning_second_allocations": stats1[2] - stats0[2],
                                         "hex_order": hex_order_counts()},
-                       "render_path": "staged" if R.STAGED_ONLY else "gs4d_render_forward / gs4d_render_backward (one call per direction)"},
+                       "render_path": "staged" if R.STAGED_ONLY else
+                                      "gs4d_render_forward / gs4d_render_backward (one call per direction)" +
+                                      (", issued back to back by renderer.render_l1_step" if FUSED_STEP and VPG == 1 else
+                                       ", through autograd")},
             "roofline": roofline, "rooflines": rooflines, "cpu_baseline": cpu, "render_fps": render_fps,
             "stages_ms": {k: round(v, 4) for k, v in stages.items()},
             "stages_note": f"{dominant} timed with HIP events inside the timed region; the other stages in a separate untimed pass",

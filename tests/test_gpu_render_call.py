@@ -167,6 +167,44 @@ def test_stage_hooks_fire_with_final_gradients():
     assert torch.equal(seen["ftw"], deform.deformation_net.force_time_embed.weight.grad)
 
 
+def test_step_call_equals_autograd_backward():
+    """renderer.render_l1_step (forward + L1 + backward issued back to back, gradients written to .grad without an
+    autograd graph) against render_with_l1(...) followed by (scale * loss).backward(): same library calls, so loss,
+    image and every gradient agree bit for bit (plane gradients: float atomics, 1e-6); a second call accumulates; the
+    staged fallback of the step call gives the same again."""
+    R, pc, deform, cam, bg, target = small_scene(seed=11)
+    names, params = named(pc, deform)
+    for scale in (1.0, 0.25):
+        def autograd():
+            loss, image, ssp, vis, radii, depth = R.render_with_l1(cam, pc, deform, bg, target)
+            (loss * scale if scale != 1.0 else loss).backward()
+            return loss.detach().clone(), image.detach().clone(), ssp.grad.clone(), radii.clone(), vis.clone()
+
+        def step():
+            loss, image, ssp, vis, radii, depth = R.render_l1_step(cam, pc, deform, bg, target, loss_scale=scale)
+            assert not loss.requires_grad and not image.requires_grad
+            return loss.clone(), image.clone(), ssp.grad.clone(), radii.clone(), vis.clone()
+
+        a, ga = run(R, False, autograd, params)
+        b, gb = run(R, False, step, params)
+        c, gc = run(R, True, step, params)         # the step call's fallback: staged render + autograd
+        for x, y, z in zip(a, b, c):
+            assert torch.equal(x, y) and torch.equal(x, z)
+        assert_same(params, names, ga, gb)
+        assert_same(params, names, ga, gc)
+        assert sum(g is not None for g in gb) >= 5 + 12 + 2 + 2 + 16
+
+    def twice():
+        R.render_l1_step(cam, pc, deform, bg, target)
+        R.render_l1_step(cam, pc, deform, bg, target)
+
+    one, g1 = run(R, False, lambda: R.render_l1_step(cam, pc, deform, bg, target) and None, params)
+    two, g2 = run(R, False, twice, params)
+    for n, u, v in zip(names, g1, g2):
+        if u is not None:
+            assert float((v - 2 * u).abs().max()) <= 2e-6 * float(u.abs().max()) + 1e-12, n
+
+
 def test_c2_headline_scene_one_call_equals_staged():
     """BASELINE.json configs[1] as bench.py builds it: the default path of render_with_l1 against the staged path."""
     Wl, R, F = pkg("workload"), pkg("renderer"), pkg("fused")
