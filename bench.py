@@ -512,6 +512,17 @@ def main():
         def opt_step():
             v = next_view()
             cam, target = v.cam, v.target
+            if FUSED_STEP:
+                # render + L1 + backward in one go; the regularisers see only the (replicated) planes, so every rank adds
+                # their gradient locally AFTER the exchange of the render-path gradients
+                R.render_l1_step(cam, pc, deform, bg, target, loss_scale=1.0 / world if dp else 1.0, shs_grad_hook=hook)
+                if dp:
+                    bucket.all_reduce()
+                reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"].backward()
+                opt.step()
+                for p in all_params:
+                    p.grad = None
+                return
             image, *_ = R.render(cam, pc, deform, bg, shs_grad_hook=hook)
             regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
             if not dp:
