@@ -4,6 +4,7 @@ tag=$1; r=$2
 src=gpurun_out/prof_$tag
 cp $src/kernel_stats.csv profiles/${r}_bench_c2_train_kernel_stats.csv
 for n in p1 p2 p3 pf pw; do cp $src/pmc_$n.txt profiles/${r}_pmc_$n.txt; done
+cp $src/pmc_lds.json profiles/${r}_pmc_lds.json
 cp $src/pmc_traffic.json profiles/${r}_pmc_traffic.json
 for c in 2 3 4 5; do cp $src/bench_c$c.json profiles/${r}_bench_c${c}_train.json; done
 python3 - $r <<'PY'
