@@ -102,6 +102,70 @@ __global__ __launch_bounds__(256) void hexplane_forward_kernel(
     }
 }
 
+// The same gather with the corner arithmetic done ONCE per (point, plane): with C/4 lanes per point every lane of the
+// kernel above repeats the twelve corner_of evaluations of its point (about 45 VALU instructions each against the ~20
+// of the blend that uses them: the counters showed the vector ALU busy 60 % of the time at C = 32 and 75 % at C = 128,
+// waves waiting 14 %).  A workgroup of 256 lanes owns 256 / (C/4) consecutive points: their normalised coordinates go
+// to LDS, then the (point, plane) pairs are dealt to the lanes and each leaves its four texel indices and four weights in
+// LDS, where the point's lanes read them back as two broadcast ds_read_b128.  Same arithmetic by another lane: the
+// features are bit-identical.  Used when C >= 16 (four lanes per point or more).
+__device__ __forceinline__ int pair_a(int i) { return (0x211000 >> (4 * i)) & 15; }      // kPairA / kPairB without a table read
+__device__ __forceinline__ int pair_b(int i) { return (0x332321 >> (4 * i)) & 15; }
+
+__global__ __launch_bounds__(256) void hexplane_forward_shared_kernel(
+    int P, int C, int L, int lpp_shift, PlaneTable T, const float* __restrict__ aabb, const float* __restrict__ xyz,
+    const float* __restrict__ time, const float* __restrict__ force, const float* __restrict__ ft_w,
+    const float* __restrict__ ft_b, int use_time, int use_force, float* __restrict__ tprime,
+    float* __restrict__ feat, int ldf)
+{
+    extern __shared__ float4 s_hex[];                    // [ppw] coordinates | [ppw * L * 6][2] corner sets
+    const int ppw = 256 >> lpp_shift;                    // points of this workgroup
+    const int np = L * 6;
+    float4* s_pts = s_hex;
+    float4* s_set = s_hex + ppw;
+    const int p0 = blockIdx.x * ppw;
+    if ((int)threadIdx.x < ppw) {
+        const int p = p0 + (int)threadIdx.x;
+        float pts[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p < P) {
+            load_coords(xyz, aabb, time, force, ft_w, ft_b, use_time, use_force, p, pts);
+            tprime[p] = pts[3];
+        }
+        s_pts[threadIdx.x] = make_float4(pts[0], pts[1], pts[2], pts[3]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ppw * np; e += 256) {
+        const int lp = e / np, pl = e - lp * np, i = pl % 6;
+        const float* pp = reinterpret_cast<const float*>(&s_pts[lp]);
+        const Corner c = corner_of(pp[pair_a(i)], pp[pair_b(i)], T.w[pl], T.h[pl]);
+        s_set[2 * e] = make_float4(__int_as_float(c.i00), __int_as_float(c.i01), __int_as_float(c.i10), __int_as_float(c.i11));
+        s_set[2 * e + 1] = make_float4(c.w00, c.w01, c.w10, c.w11);
+    }
+    __syncthreads();
+    const int lp = (int)threadIdx.x >> lpp_shift;
+    const int sub = (int)threadIdx.x & ((1 << lpp_shift) - 1);
+    const int p = p0 + lp;
+    if (p >= P) return;
+    const int q = C >> 2;
+    const float4* __restrict__ mine = s_set + 2 * (size_t)lp * np;
+    for (int l = 0; l < L; l++) {
+        float4 acc = make_float4(1.f, 1.f, 1.f, 1.f);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const int pl = l * 6 + i;
+            const float4 ci = mine[2 * pl], cw = mine[2 * pl + 1];
+            const float4* __restrict__ base = reinterpret_cast<const float4*>(T.p[pl]) + sub;
+            const float4 f00 = base[(size_t)__float_as_int(ci.x) * q], f01 = base[(size_t)__float_as_int(ci.y) * q];
+            const float4 f10 = base[(size_t)__float_as_int(ci.z) * q], f11 = base[(size_t)__float_as_int(ci.w) * q];
+            acc.x *= f00.x * cw.x + f01.x * cw.y + f10.x * cw.z + f11.x * cw.w;
+            acc.y *= f00.y * cw.x + f01.y * cw.y + f10.y * cw.z + f11.y * cw.w;
+            acc.z *= f00.z * cw.x + f01.z * cw.y + f10.z * cw.z + f11.z * cw.w;
+            acc.w *= f00.w * cw.x + f01.w * cw.y + f10.w * cw.z + f11.w * cw.w;
+        }
+        reinterpret_cast<float4*>(feat + (size_t)p * ldf + l * C)[sub] = acc;
+    }
+}
+
 // Backward, common part: for one (point, level, channel) sample the six planes and return
 // gi[i] = dL/dfeat * product of the other five samples, plus the coordinate derivatives.
 struct SixSamples { float gi[6], ddx[6], ddy[6]; };
@@ -221,6 +285,109 @@ __global__ __launch_bounds__(256) void hexplane_backward_point_kernel(
             }
             const float4 g = *reinterpret_cast<const float4*>(dfeat + (size_t)p * ldf + l * C + 4 * sub);
             // product of the other five planes via prefix / suffix products (no division)
+            float4 pre[6], suf[6];
+            pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
+            suf[5] = pre[0];
+#pragma unroll
+            for (int i = 1; i < 6; i++) pre[i] = make_float4(pre[i - 1].x * v[i - 1].x, pre[i - 1].y * v[i - 1].y, pre[i - 1].z * v[i - 1].z, pre[i - 1].w * v[i - 1].w);
+#pragma unroll
+            for (int i = 4; i >= 0; i--) suf[i] = make_float4(suf[i + 1].x * v[i + 1].x, suf[i + 1].y * v[i + 1].y, suf[i + 1].z * v[i + 1].z, suf[i + 1].w * v[i + 1].w);
+            float4* __restrict__ out = reinterpret_cast<float4*>(gsix + ((size_t)p * L + l) * 6 * C) + sub;
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const float4 gi = make_float4(g.x * pre[i].x * suf[i].x, g.y * pre[i].y * suf[i].y, g.z * pre[i].z * suf[i].z, g.w * pre[i].w * suf[i].w);
+                out[(size_t)i * q4] = gi;
+                dpts[kPairA[i]] += (gi.x * dx[i].x + gi.y * dx[i].y) + (gi.z * dx[i].z + gi.w * dx[i].w);
+                dpts[kPairB[i]] += (gi.x * dy[i].x + gi.y * dy[i].y) + (gi.z * dy[i].z + gi.w * dy[i].w);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+        for (int off = lanes >> 1; off >= 1; off >>= 1) dpts[a] += __shfl_xor(dpts[a], off, 64);
+    if (live && sub == 0) dcoord[p] = make_float4(dpts[0], dpts[1], dpts[2], dpts[3]);
+}
+
+// The point kernel with the corner sets of a workgroup's points shared through LDS (see hexplane_forward_shared_kernel):
+// per (point, plane) the four texel indices, the four weights and the four coordinate-derivative factors are computed by
+// ONE lane instead of by each of the point's C/4 lanes.  Same arithmetic, bit-identical outputs.  C >= 16.
+__global__ __launch_bounds__(256) void hexplane_backward_point_shared_kernel(
+    int P, int C, int L, int lpp_shift, PlaneTable T, HexBins B, const float* __restrict__ aabb,
+    const float* __restrict__ xyz, const float* __restrict__ tprime, const float* __restrict__ dfeat, int ldf,
+    float4* __restrict__ dcoord, float* __restrict__ gsix, int* __restrict__ hist, int* __restrict__ rank,
+    int* __restrict__ key, int do_rank)
+{
+    extern __shared__ float4 s_hex[];                    // [ppw] coordinates | [ppw * L * 6][3] corner sets
+    const int lanes = 1 << lpp_shift;
+    const int ppw = 256 >> lpp_shift;
+    const int np = L * 6;
+    float4* s_pts = s_hex;
+    float4* s_set = s_hex + ppw;
+    const int p0 = blockIdx.x * ppw;
+    if ((int)threadIdx.x < ppw) {
+        const int pp = p0 + (int)threadIdx.x;
+        float c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pp < P) {
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float lo = aabb[a], hi = aabb[3 + a];
+                c[a] = (xyz[3 * (size_t)pp + a] - lo) * (2.0f / (hi - lo)) - 1.0f;
+            }
+            c[3] = tprime[pp];
+        }
+        s_pts[threadIdx.x] = make_float4(c[0], c[1], c[2], c[3]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < ppw * np; e += 256) {
+        const int lq = e / np, pl = e - lq * np, i = pl % 6;
+        const float* pp = reinterpret_cast<const float*>(&s_pts[lq]);
+        const Corner c = corner_of(pp[pair_a(i)], pp[pair_b(i)], T.w[pl], T.h[pl]);
+        s_set[3 * e] = make_float4(__int_as_float(c.i00), __int_as_float(c.i01), __int_as_float(c.i10), __int_as_float(c.i11));
+        s_set[3 * e + 1] = make_float4(c.w00, c.w01, c.w10, c.w11);
+        s_set[3 * e + 2] = make_float4((1.f - c.wy) * c.sx, c.wy * c.sx, (1.f - c.wx) * c.sy, c.wx * c.sy);
+    }
+    __syncthreads();
+    const int lp = (int)threadIdx.x >> lpp_shift;
+    const int sub = (int)threadIdx.x & (lanes - 1);
+    const int p = p0 + lp;
+    const bool live = p < P;
+    const int q4 = C >> 2;
+    const float4 my = s_pts[lp];
+    const float pts[4] = {my.x, my.y, my.z, my.w};
+    float dpts[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live && do_rank) {                      // rank the point inside its cell of every level's sort planes
+        for (int ls = sub; ls < L * HEX_SORTS; ls += lanes) {    // one (level, sort) per lane of the point
+            const int l = ls / HEX_SORTS, s = ls - l * HEX_SORTS;
+            const int i = B.plane[s], pl = l * 6 + i;
+            float u = 0.f, v = 0.f;
+#pragma unroll
+            for (int k = 0; k < 6; k++)
+                if (k == i) { u = pts[kPairA[k]]; v = pts[kPairB[k]]; }
+            const Corner c = corner_of(u, v, T.w[pl], T.h[pl]);
+            const int k = hex_key(B, l, s, c.x0, c.y0, T.w[pl], T.h[pl]);
+            key[(size_t)ls * P + p] = k;
+            rank[(size_t)ls * P + p] = atomicAdd(&hist[(size_t)ls * B.nbins + k], 1);
+        }
+    }
+    if (live) {
+        const float4* __restrict__ mine = s_set + 3 * (size_t)lp * np;
+        for (int l = 0; l < L; l++) {
+            float4 v[6], dx[6], dy[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const int pl = l * 6 + i;
+                const float4 ci = mine[3 * pl], cw = mine[3 * pl + 1], ca = mine[3 * pl + 2];
+                const float4* __restrict__ base = reinterpret_cast<const float4*>(T.p[pl]) + sub;
+                const float4 f00 = base[(size_t)__float_as_int(ci.x) * q4], f01 = base[(size_t)__float_as_int(ci.y) * q4];
+                const float4 f10 = base[(size_t)__float_as_int(ci.z) * q4], f11 = base[(size_t)__float_as_int(ci.w) * q4];
+#define HEX_COMP(m)                                                                                   \
+                v[i].m = f00.m * cw.x + f01.m * cw.y + f10.m * cw.z + f11.m * cw.w;                   \
+                dx[i].m = (f01.m - f00.m) * ca.x + (f11.m - f10.m) * ca.y;                             \
+                dy[i].m = (f10.m - f00.m) * ca.z + (f11.m - f01.m) * ca.w;
+                HEX_COMP(x) HEX_COMP(y) HEX_COMP(z) HEX_COMP(w)
+#undef HEX_COMP
+            }
+            const float4 g = *reinterpret_cast<const float4*>(dfeat + (size_t)p * ldf + l * C + 4 * sub);
             float4 pre[6], suf[6];
             pre[0] = make_float4(1.f, 1.f, 1.f, 1.f);
             suf[5] = pre[0];
@@ -511,6 +678,13 @@ __global__ __launch_bounds__(256) void hexplane_coord_reduce_kernel(int P, const
 
 }  // namespace
 
+// GS4D_HEX_CORNERS=private (tests / experiments): every lane computes its point's corner sets itself, as before round 3
+static bool hex_private_corners()
+{
+    static const bool v = [] { const char* e = getenv("GS4D_HEX_CORNERS"); return e && e[0] == 'p'; }();
+    return v;
+}
+
 HexBins gs4d_hex_bins(const gs4d_deform_desc* d)
 {
     HexBins B = {};
@@ -558,9 +732,17 @@ int gs4d_hex_launch_forward(const gs4d_deform_desc* d, int P, const float* point
     int lpp_shift = 0;
     while ((1 << lpp_shift) < d->C / 4) lpp_shift++;
     const size_t threads = (size_t)P << lpp_shift;
-    hipLaunchKernelGGL(hexplane_forward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, d->C,
-                       d->L, lpp_shift, T, d->aabb, points, time, force, d->ft_w, d->ft_b, d->use_time,
-                       d->use_force, tprime, feat, ldf);
+    if (lpp_shift >= 2 && !hex_private_corners()) {      // four lanes per point or more: corner sets shared through LDS
+        const int ppw = 256 >> lpp_shift;
+        const size_t lds = sizeof(float4) * ((size_t)ppw + 2 * (size_t)ppw * d->L * 6);      // <= 49 KB (64 points, 4 levels)
+        hipLaunchKernelGGL(hexplane_forward_shared_kernel, dim3((unsigned)(((size_t)P + ppw - 1) / ppw)), dim3(256), lds, s, P,
+                           d->C, d->L, lpp_shift, T, d->aabb, points, time, force, d->ft_w, d->ft_b, d->use_time,
+                           d->use_force, tprime, feat, ldf);
+    } else {
+        hipLaunchKernelGGL(hexplane_forward_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, P, d->C,
+                           d->L, lpp_shift, T, d->aabb, points, time, force, d->ft_w, d->ft_b, d->use_time,
+                           d->use_force, tprime, feat, ldf);
+    }
     GS4D_LAUNCH_CHECK("hexplane_forward", 0, s);
     return GS4D_OK;
 }
@@ -589,6 +771,11 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
         lanes_shift == 2 ? hexplane_backward_reduce_kernel<2> : lanes_shift == 3 ? hexplane_backward_reduce_kernel<3> :
         lanes_shift == 4 ? hexplane_backward_reduce_kernel<4> : lanes_shift == 5 ? hexplane_backward_reduce_kernel<5> :
                            hexplane_backward_reduce_kernel<6>;
+    static bool point_attr = false;
+    if (!point_attr) {
+        GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)hexplane_backward_point_shared_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        point_attr = true;
+    }
     static bool reduce_attr[8] = {};
     if (!reduce_attr[lanes_shift]) {
         GS4D_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
@@ -606,9 +793,17 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
         const float* pts_b = points + 3 * p0;
         const float* tp_b = tprime + p0;
         const size_t threads = (size_t)n << lpp_shift;
-        hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n,
-                           d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * (size_t)ldf, ldf,
-                           (float4*)dxyz_hex + p0, gsix, hist, rank, key, reuse_order ? 0 : 1);
+        if (lpp_shift >= 2 && !hex_private_corners()) {
+            const int ppw = 256 >> lpp_shift;
+            const size_t plds = sizeof(float4) * ((size_t)ppw + 3 * (size_t)ppw * d->L * 6);   // <= 74 KB (64 points, 4 levels)
+            hipLaunchKernelGGL(hexplane_backward_point_shared_kernel, dim3((unsigned)((n + ppw - 1) / ppw)), dim3(256), plds, s, n,
+                               d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * (size_t)ldf, ldf,
+                               (float4*)dxyz_hex + p0, gsix, hist, rank, key, reuse_order ? 0 : 1);
+        } else {
+            hipLaunchKernelGGL(hexplane_backward_point_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, n,
+                               d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * (size_t)ldf, ldf,
+                               (float4*)dxyz_hex + p0, gsix, hist, rank, key, reuse_order ? 0 : 1);
+        }
         if (reuse_order) {
             const size_t ne = (size_t)d->L * HEX_SORTS * n;
             hipLaunchKernelGGL(hexplane_rec_from_order_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, n, d->L,

@@ -45,6 +45,27 @@ def test_small_batches_reproduce_single_batch_gradients(tmp_path):
     print("plane gradients, 10 batches vs 1: max rel err", worst)
 
 
+def test_shared_corner_sets_change_no_result(tmp_path):
+    """Round 3: the gather and the per-point backward kernel compute the corner sets of a point once per (point, plane)
+    and share them through LDS (csrc/hexplane.hip, C >= 16); GS4D_HEX_CORNERS=private keeps the per-lane form.  Same
+    arithmetic by another lane: a child in the per-lane form must reproduce this process's gradients -- everything but
+    the plane gradients bit for bit (the input gradients depend on every forward value), the planes to the rounding of
+    their float atomics."""
+    import hex_batch_child
+    want = hex_batch_child.run()
+    out = str(tmp_path / "g.npz")
+    env = dict(os.environ, GS4D_HEX_CORNERS="private")
+    r = subprocess.run([sys.executable, os.path.join(HERE, "hex_batch_child.py"), out], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    for k, w in want.items():
+        if "grids" in k:
+            err = float(np.abs(got[k] - w).max() / max(np.abs(w).max(), 1e-30))
+            assert err <= 2e-6, (k, err)
+        else:
+            np.testing.assert_array_equal(got[k], w, err_msg=k)
+
+
 def test_force_blend_shape_1p2m_points_bounded_scratch_properties():
     # this process runs its other tests with the default batch size; the property run needs several batches at a size
     # the box handles quickly, so it goes to a child as well
