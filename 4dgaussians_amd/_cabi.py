@@ -61,6 +61,14 @@ def forward_stats():
     return tuple(x.value for x in v)
 
 
+def speculation_stats():
+    """(issued, reissued): gs4d_render_forward calls of this thread whose binning + blend went into the stream before
+    num_rendered had been read, and how many of those were issued again because the count exceeded the capacity."""
+    v = [C.c_ulonglong(0) for _ in range(2)]
+    lib().gs4d_speculation_stats(*(C.byref(x) for x in v))
+    return tuple(x.value for x in v)
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().gs4d_last_error().decode(errors="replace")

@@ -26,6 +26,9 @@ struct ThreadState {
     bool tried = false;
     uint32_t seq = 0;
     size_t last_R = 0;
+    size_t recent_R[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last eight counts: the speculative launch sizes for their maximum
+    unsigned recent_i = 0;
+    unsigned long long speculated = 0, respun = 0;  // forwards whose binning + blend were issued before the count was read / of those, re-issued
     unsigned long long fast = 0, slow = 0;      // how often the count arrived through the mailbox / the copy + sync path
     unsigned long long regrow = 0;              // forwards whose speculative binning chunk was too small (second allocation)
 };
@@ -305,6 +308,12 @@ void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsi
     if (regrow) *regrow = t_state.regrow;
 }
 
+void gs4d_speculation_stats(unsigned long long* issued, unsigned long long* reissued)
+{
+    if (issued) *issued = t_state.speculated;
+    if (reissued) *reissued = t_state.respun;
+}
+
 void gs4d_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -352,16 +361,23 @@ size_t gs4d_backward_scratch_bytes(int R)
     return gs4d_align_up((size_t)R * GS4D_GRAD_ROW * sizeof(float), 256) + 256 + ((size_t)R / 64 + 64) * sizeof(uint32_t) + 256;
 }
 
-int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
-                           gs4d_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
-                           int width, int height, const float* means3D, const float* shs,
-                           const float* colors_precomp, const float* opacities, const float* scales,
-                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
-                           float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
-                           void* stream, int* num_rendered)
+// speculate != 0 (the composite render call, csrc/render.hip): binning and blend are issued BEFORE the host has read
+// num_rendered, laid out and sized for the largest of the thread's last eight counts + 1/8, with the count taken from
+// device memory by the kernels; the host then reads the mailbox as always and re-issues the two stages only if the count
+// exceeded that capacity (the speculative kernels do nothing in that case).  The GPU no longer idles for the round trip.
+// *layout_rendered = the count the binning chunk is laid out for (the backward needs it to find the arrays again).
+}  // extern "C"
+int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
+                                gs4d_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                int width, int height, const float* means3D, const float* shs,
+                                const float* colors_precomp, const float* opacities, const float* scales,
+                                float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
+                                void* stream, int* num_rendered, int speculate, int* layout_rendered)
 {
     GS4D_TRACE_SCOPE("gs4d_rasterize_forward");
+    if (layout_rendered) *layout_rendered = 0;
     hipStream_t s = (hipStream_t)stream;
     const int debug = debug_arg & 1;                // bit 1 (GS4D_FORWARD_ONLY): see include/gs4d.h
     if (num_rendered) *num_rendered = 0;
@@ -434,10 +450,15 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     if (rc) return rc;
 
     const bool with_ckpt = !(debug_arg & GS4D_FORWARD_ONLY);
+    static const bool spec_off = [] { const char* e = getenv("GS4D_NO_SPECULATION"); return e && e[0] && e[0] != '0'; }();
+    speculate = speculate && !debug && !spec_off;
     char* bchunk = nullptr;
     size_t guess_R = 0;
     if (ts.last_R) {
-        guess_R = ts.last_R + ts.last_R / 8 + 4096;
+        size_t base_R = ts.last_R;
+        if (speculate)
+            for (size_t r : ts.recent_R) base_R = r > base_R ? r : base_R;
+        guess_R = base_R + base_R / 8 + 4096;
         gs4d_note_alloc();
         bchunk = (char*)binning_alloc(binning_ctx, BinningState::required(guess_R, with_ckpt));
         if (gs4d_trace_on()) gs4d_trace_checkpoint("binning allocator callback (speculative size)");
@@ -446,6 +467,22 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
             gs4d_set_error("binning allocator returned NULL");
             return GS4D_EALLOC;
         }
+    }
+
+    const float* features = colors_precomp ? colors_precomp : g.rgb;
+    bool spec_issued = false;
+    if (speculate && bchunk && guess_R <= 0x7fffffffu) {
+        char* c = bchunk;
+        BinningState bs = BinningState::from_chunk(c, guess_R, sort_passes(width, height), with_ckpt);
+        rc = gs4d_launch_binning(P, (int)guess_R, width, height, radii, g, bs, im, debug, s, g.counters);
+        if (!rc)
+            rc = gs4d_launch_blend_forward(width, height, g, bs, im, features, background, out_color, out_depth, with_ckpt, debug, s);
+        if (rc) {
+            (void)hipStreamSynchronize(s);                                      // no post may arrive after this call has returned
+            return rc;
+        }
+        spec_issued = true;
+        ts.speculated++;
     }
 
     uint32_t host_counters[2] = {0, 0};
@@ -492,6 +529,14 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
     }
     const int R = (int)host_counters[0];
     if (num_rendered) *num_rendered = R;
+    ts.recent_R[ts.recent_i++ & 7u] = (size_t)R;
+    if (spec_issued && (size_t)R <= guess_R) {             // what is in the stream already is the result
+        ts.last_R = (size_t)R;
+        if (layout_rendered) *layout_rendered = (int)guess_R;
+        return GS4D_OK;
+    }
+    if (spec_issued) ts.respun++;
+    if (layout_rendered) *layout_rendered = R;
 
     if (!bchunk || (size_t)R > guess_R) {
         if (bchunk) ts.regrow++;
@@ -504,21 +549,40 @@ int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_
 
     rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);
     if (rc) return rc;
-    const float* features = colors_precomp ? colors_precomp : g.rgb;
     return gs4d_launch_blend_forward(width, height, g, b, im, features, background, out_color, out_depth,
                                      !(debug_arg & GS4D_FORWARD_ONLY), debug, s);
 }
+extern "C" {
 
-int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
-                            const float* background, int width, int height, const float* means3D, const float* shs,
-                            const float* colors_precomp, const float* scales, float scale_modifier,
-                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
-                            const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
-                            const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
-                            float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
-                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                            void* stream)
+int gs4d_rasterize_forward(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
+                           gs4d_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                           int width, int height, const float* means3D, const float* shs,
+                           const float* colors_precomp, const float* opacities, const float* scales,
+                           float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                           const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                           float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
+                           void* stream, int* num_rendered)
+{
+    // the binning chunk of this entry point is laid out for num_rendered exactly (gs4d_rasterize_backward and
+    // gs4d_state_view_get find its arrays from that number alone): no speculative launch here
+    return gs4d_rasterize_forward_spec(geom_alloc, geom_ctx, binning_alloc, binning_ctx, image_alloc, image_ctx, P, D, M, background,
+                                       width, height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations,
+                                       cov3D_precomp, viewmatrix, projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color,
+                                       out_depth, radii, debug_arg, stream, num_rendered, 0, nullptr);
+}
+
+}  // extern "C"
+// layout_rendered: the count the forward laid the binning chunk out for (gs4d_rasterize_forward_spec); R otherwise
+int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
+                                   const float* background, int width, int height, const float* means3D, const float* shs,
+                                   const float* colors_precomp, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                   const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                   const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                                   float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                                   float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                                   void* stream, int layout_rendered)
 {
     GS4D_TRACE_SCOPE("gs4d_rasterize_backward");
     hipStream_t s = (hipStream_t)stream;
@@ -539,7 +603,8 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
     char* ichunk = img_buffer;
     ImageState im = ImageState::from_chunk(ichunk, (size_t)width * height, gx * gy);
     char* bchunk = binning_buffer;
-    BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height));
+    if (layout_rendered < R) { gs4d_set_error("gs4d_rasterize_backward: the binning chunk is laid out for %d instances, fewer than the %d rendered", layout_rendered, R); return GS4D_EINVAL; }
+    BinningState b = BinningState::from_chunk(bchunk, (size_t)layout_rendered, sort_passes(width, height));
 
     gs4d_note_alloc();
     float* inst_grad = (float*)scratch_alloc(scratch_ctx, gs4d_backward_scratch_bytes(R));
@@ -555,6 +620,25 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
                                      scale_modifier, cov3D, viewmatrix, projmatrix, tan_fovx, tan_fovy, campos, g, b,
                                      inst_grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
                                      dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, s);
+}
+extern "C" {
+
+int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                            const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                            const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                            const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                            float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                            float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                            void* stream)
+{
+    return gs4d_rasterize_backward_layout(scratch_alloc, scratch_ctx, P, D, M, R, background, width, height, means3D, shs,
+                                          colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
+                                          campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix,
+                                          dL_dpix_depth, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
+                                          dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, stream, R);
 }
 
 int gs4d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,

@@ -35,6 +35,18 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid)
     return ((uint64_t)hi << 32) | (uint64_t)lo;
 }
 
+// The number of instances of a launch: known to the host (R_dev == nullptr, R_host exact), or still on the device when the
+// forward issued this launch SPECULATIVELY, sized for at most R_host instances, before it had read num_rendered (api.hip):
+// then the count is counters[0], written by scan_block_sums_kernel earlier in the stream.  More instances than the launch
+// was sized for -> GS4D_R_OVERFLOW: the kernel does nothing (the host re-issues the stage with the exact size).
+#define GS4D_R_OVERFLOW 0xffffffffu
+__device__ __forceinline__ uint32_t resolve_R(uint32_t R_host, const uint32_t* __restrict__ R_dev)
+{
+    if (!R_dev) return R_host;
+    const uint32_t r = *R_dev;
+    return r > R_host ? GS4D_R_OVERFLOW : r;
+}
+
 // ------------------------------------------------------------------ block-sum scan (1 workgroup)
 // block_offsets = exclusive scan of block_sums (bits 0..30; bit 31 is the workgroup's prefilter flag); counters[0] =
 // total, counters[1] = OR of the flags (both words are written here: nothing clears them).  n is ceil(P/256)
@@ -96,7 +108,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
     const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
     const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ point_offsets,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint2* __restrict__ ranges, int ntiles,
-    uint2* __restrict__ seg_owner, int seg_slots)
+    uint2* __restrict__ seg_owner, int seg_slots, uint32_t cap, const uint32_t* __restrict__ R_dev)
 {
     // the tile ranges start as (0, 0) (empty tile) and the backward's segment slots as "nobody"; this launch is the first
     // of the binning stage and has lanes to spare
@@ -104,6 +116,8 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
         ranges[t] = make_uint2(0u, 0u);
     for (int t = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x; t < seg_slots; t += gridDim.x * GS4D_PRE_BLOCK)
         seg_owner[t] = make_uint2(~0u, 0u);
+    // speculative launch with more instances than it was sized for: the tiles stay empty, nothing is emitted
+    if (R_dev && resolve_R(cap, R_dev) == GS4D_R_OVERFLOW) return;
     __shared__ uint32_t s_incl[GS4D_PRE_BLOCK];   // inclusive scan of counts inside the workgroup
     __shared__ uint32_t s_wave[GS4D_PRE_BLOCK / 64];
     __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
@@ -173,10 +187,13 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
 // A tile is 2048 keys: wave w owns keys [512w, 512w+512), lane l handles key 512w + 64r + l in
 // round r, so (wave, round, lane) order == memory order, which is what makes the sort stable.
 
-__global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_hist_kernel(uint32_t R, int shift,
+__global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_hist_kernel(uint32_t R_host, int shift,
                                                                       const uint64_t* __restrict__ keys,
-                                                                      uint32_t* __restrict__ hist, uint32_t ntiles)
+                                                                      uint32_t* __restrict__ hist, uint32_t ntiles,
+                                                                      const uint32_t* __restrict__ R_dev)
 {
+    const uint32_t R = resolve_R(R_host, R_dev);
+    if (R == GS4D_R_OVERFLOW || R == 0u) return;           // (speculative launches only: the host never launches with R = 0)
     __shared__ uint32_t s_h[256];
     s_h[threadIdx.x] = 0;
     __syncthreads();
@@ -224,10 +241,12 @@ __global__ __launch_bounds__(256) void sort_scan_kernel(uint32_t ntiles, uint32_
 }
 
 __global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_scatter_kernel(
-    uint32_t R, int shift, const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t R_host, int shift, const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, const uint32_t* __restrict__ hist,
-    const uint32_t* __restrict__ digit_totals, uint32_t ntiles)
+    const uint32_t* __restrict__ digit_totals, uint32_t ntiles, const uint32_t* __restrict__ R_dev)
 {
+    const uint32_t R = resolve_R(R_host, R_dev);
+    if (R == GS4D_R_OVERFLOW || blockIdx.x * GS4D_SORT_TILE >= R) return;   // uniform: a tile beyond the last instance
     __shared__ uint32_t s_cnt[4][256];        // per-wave digit counts -> exclusive offsets inside the tile
     __shared__ uint32_t s_digit_start[256];   // first staged slot of each digit inside the tile
     __shared__ uint32_t s_global[256];        // global output position of that first slot
@@ -351,10 +370,12 @@ __global__ __launch_bounds__(GS4D_SORT_THREADS) void sort_scatter_kernel(
 // passes chunk by chunk through the two global buffers (slow, correct).
 #define SEG_CAP 2048
 
-__global__ __launch_bounds__(256) void tile_bounds_kernel(uint32_t R, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges)
+__global__ __launch_bounds__(256) void tile_bounds_kernel(uint32_t R_host, const uint64_t* __restrict__ keys, uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ R_dev)
 {
+    const uint32_t R = resolve_R(R_host, R_dev);
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= R) return;
+    if (R == GS4D_R_OVERFLOW || idx >= R) return;
     const uint32_t tile = (uint32_t)(keys[idx] >> 32);
     if (idx == 0)
         ranges[tile].x = 0;
@@ -759,11 +780,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // ------------------------------------------------------------------ tile ranges (six-pass LSD order only)
 // ranges[tile] = [first, last+1) in the sorted list (zeroed beforehand by emit_keys_kernel)
-__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint64_t* __restrict__ keys_sorted,
-                                                          uint2* __restrict__ ranges)
+__global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R_host, const uint64_t* __restrict__ keys_sorted,
+                                                          uint2* __restrict__ ranges, const uint32_t* __restrict__ R_dev)
 {
+    const uint32_t R = resolve_R(R_host, R_dev);
     const uint32_t idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= R) return;
+    if (R == GS4D_R_OVERFLOW || idx >= R) return;
     const uint32_t tile = (uint32_t)(keys_sorted[idx] >> 32);
     if (idx == 0)
         ranges[tile].x = 0;
@@ -784,7 +806,7 @@ __global__ __launch_bounds__(256) void tile_ranges_kernel(uint32_t R, const uint
 // hist must hold 256 * gs4d_sort_blocks(R) + 256 words.
 int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
                           uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
-                          int debug, hipStream_t s)
+                          int debug, hipStream_t s, const uint32_t* R_dev)
 {
     const uint32_t ntiles = gs4d_sort_blocks((size_t)R);
     uint32_t* digit_totals = hist + (size_t)256 * ntiles;
@@ -794,10 +816,10 @@ int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_
     for (int p = 0; p < passes; p++) {
         uint64_t* kout = keys_tmp[p & 1];
         uint32_t* vout = vals_tmp[p & 1];
-        hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, first_shift + 8 * p, kin, hist, ntiles);
+        hipLaunchKernelGGL(sort_hist_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, first_shift + 8 * p, kin, hist, ntiles, R_dev);
         hipLaunchKernelGGL(sort_scan_kernel, dim3(256), dim3(256), 0, s, ntiles, hist, digit_totals);
         hipLaunchKernelGGL(sort_scatter_kernel, dim3(ntiles), dim3(GS4D_SORT_THREADS), 0, s, R, first_shift + 8 * p, kin, vin, kout,
-                           vout, hist, digit_totals, ntiles);
+                           vout, hist, digit_totals, ntiles, R_dev);
         GS4D_LAUNCH_CHECK("radix_sort_pass", debug, s);
         kin = kout;
         vin = vout;
@@ -816,8 +838,10 @@ int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t 
     return GS4D_OK;
 }
 
+// R_dev == nullptr: R is num_rendered.  Otherwise the speculative form: R is the capacity the binning chunk was laid out
+// for, the kernels take the count from *R_dev (GeomState::counters) and do nothing if it exceeds R.
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
-                        int debug, hipStream_t s)
+                        int debug, hipStream_t s, const uint32_t* R_dev)
 {
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
@@ -825,7 +849,8 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     GS4D_PROF("emit_keys", s);
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                        radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
-                       im.ranges, gx * gy, b.seg_owner, b.seg_owner ? (int)b.seg_slots : 0);   // no slots on a forward-only call
+                       im.ranges, gx * gy, b.seg_owner, b.seg_owner ? (int)b.seg_slots : 0,    // no slots on a forward-only call
+                       (uint32_t)R, R_dev);
     GS4D_LAUNCH_CHECK("emit_keys", debug, s);
     }
 
@@ -838,10 +863,10 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
         GS4D_PROF("radix_sort", s);
         const int tpasses = (int)((tbits + 7) / 8);
         rc = gs4d_radix_sort_pairs((uint32_t)R, tpasses, 32, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
-                                   b.hist, &where, debug, s);
+                                   b.hist, &where, debug, s, R_dev);
         if (rc) return rc;
         hipLaunchKernelGGL(tile_bounds_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R,
-                           b.keys_tmp[where], im.ranges);
+                           b.keys_tmp[where], im.ranges, R_dev);
         const uint32_t nt = (uint32_t)(gx * gy), cap = gs4d_sort_segment_cap();
         const uint32_t wave_cap = cap < gs4d_sort_wave_cap() ? cap : gs4d_sort_wave_cap();
         hipLaunchKernelGGL(segment_depth_sort_kernel, dim3(nt + (nt + 3) / 4), dim3(256), 0, s, im.ranges, b.keys_tmp[where],
@@ -852,7 +877,7 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
         GS4D_PROF("radix_sort", s);
         const int passes = (int)((32 + tbits + 7) / 8);
         rc = gs4d_radix_sort_pairs((uint32_t)R, passes, 0, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
-                                   b.hist, &where, debug, s);
+                                   b.hist, &where, debug, s, R_dev);
         if (rc) return rc;
     }
     if (where != b.sorted) { gs4d_set_error("binning: sorted lists ended in buffer %d, layout expects %d", where, b.sorted); return GS4D_EINVAL; }
@@ -860,7 +885,7 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     if (!gs4d_sort_tile_first()) {
         GS4D_PROF("tile_ranges", s);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.keys_sorted(),
-                           im.ranges);
+                           im.ranges, R_dev);
         GS4D_LAUNCH_CHECK("tile_ranges", debug, s);
     }
     return GS4D_OK;

@@ -145,7 +145,7 @@ uint32_t gs4d_sort_segment_cap();
 uint32_t gs4d_sort_wave_cap();
 int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
                           uint64_t* const keys_tmp[2], uint32_t* const vals_tmp[2], uint32_t* hist, int* where,
-                          int debug, hipStream_t s);
+                          int debug, hipStream_t s, const uint32_t* R_dev = nullptr);
 
 // ---- stage launchers (each returns GS4D_OK or an error) ----
 int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const float* scales, float scale_modifier,
@@ -154,8 +154,27 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
                            float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s);
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
+// csrc/api.hip: the rasterizer entry points with the speculative binning launch / an explicit binning layout (csrc/render.hip)
+int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
+                                gs4d_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background,
+                                int width, int height, const float* means3D, const float* shs,
+                                const float* colors_precomp, const float* opacities, const float* scales,
+                                float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
+                                float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
+                                void* stream, int* num_rendered, int speculate, int* layout_rendered);
+int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
+                                   const float* background, int width, int height, const float* means3D, const float* shs,
+                                   const float* colors_precomp, const float* scales, float scale_modifier,
+                                   const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                                   const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy,
+                                   const int* radii, char* geom_buffer, char* binning_buffer, char* img_buffer,
+                                   const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
+                                   float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
+                                   float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                                   void* stream, int layout_rendered);
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
-                        int debug, hipStream_t s);
+                        int debug, hipStream_t s, const uint32_t* R_dev = nullptr);
 // the deferred-Gaussian counter of the backward scratch (layout: gs4d_backward_scratch_bytes)
 static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
 {

@@ -175,14 +175,17 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
     if (rc) return rc;
     FixedBlock geom{a.geom, a.geom_bytes}, image{a.image, a.image_bytes};
     BinningRelay bin{alloc, alloc_ctx, nullptr, 0};
-    int R = 0;
-    rc = gs4d_rasterize_forward(fixed_alloc, &geom, binning_alloc, &bin, fixed_alloc, &image, r->P, r->D, r->M,
-                                r->background, r->width, r->height, m3, shs, nullptr, a.opacity_a, a.scales_a,
-                                r->scale_modifier, a.rot_n, nullptr, r->viewmatrix, r->projmatrix, r->cam_pos, r->tan_fovx,
-                                r->tan_fovy, r->prefiltered, out_color, out_depth, radii, r->flags, stream, &R);
+    int R = 0, layout_R = 0;
+    // binning and blend are issued before num_rendered has been read (capacity-checked, csrc/api.hip): the state carries
+    // the count the binning chunk was laid out for
+    rc = gs4d_rasterize_forward_spec(fixed_alloc, &geom, binning_alloc, &bin, fixed_alloc, &image, r->P, r->D, r->M,
+                                     r->background, r->width, r->height, m3, shs, nullptr, a.opacity_a, a.scales_a,
+                                     r->scale_modifier, a.rot_n, nullptr, r->viewmatrix, r->projmatrix, r->cam_pos, r->tan_fovx,
+                                     r->tan_fovy, r->prefiltered, out_color, out_depth, radii, r->flags, stream, &R, 1, &layout_R);
     state->binning = bin.last;
     state->binning_bytes = bin.last_bytes;
     state->num_rendered = R;
+    state->layout_rendered = layout_R;
     if (rc) return rc;
     if (r->target)
         rc = gs4d_l1_loss_forward((size_t)3 * r->width * r->height, out_color, r->target, a.l1_scratch, loss, stream);
@@ -238,12 +241,12 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
     }
     const float *m3 = r->deform ? f.m3 : r->xyz, *shs = r->deform ? f.shs : r->shs;
     FixedBlock inst{b.inst, b.inst_bytes};
-    rc = gs4d_rasterize_backward(fixed_alloc, &inst, r->P, r->D, r->M, R, r->background, r->width, r->height, m3, shs,
-                                 nullptr, f.scales_a, r->scale_modifier, f.rot_n, nullptr, r->viewmatrix, r->projmatrix,
-                                 r->cam_pos, r->tan_fovx, r->tan_fovy, radii, f.geom, st->binning, f.image, g_img,
-                                 dL_ddepth ? dL_ddepth : b.zero_depth_img, g->dL_dmeans2D, b.dL_dconic, b.dL_dopacity,
-                                 b.dL_dcolor, b.dL_ddepth, dL_dmean3D, b.dL_dcov3D, g->d_shs, b.dL_dscale, b.dL_drot,
-                                 r->flags & 1, stream);
+    rc = gs4d_rasterize_backward_layout(fixed_alloc, &inst, r->P, r->D, r->M, R, r->background, r->width, r->height, m3, shs,
+                                        nullptr, f.scales_a, r->scale_modifier, f.rot_n, nullptr, r->viewmatrix, r->projmatrix,
+                                        r->cam_pos, r->tan_fovx, r->tan_fovy, radii, f.geom, st->binning, f.image, g_img,
+                                        dL_ddepth ? dL_ddepth : b.zero_depth_img, g->dL_dmeans2D, b.dL_dconic, b.dL_dopacity,
+                                        b.dL_dcolor, b.dL_ddepth, dL_dmean3D, b.dL_dcov3D, g->d_shs, b.dL_dscale, b.dL_drot,
+                                        r->flags & 1, stream, st->layout_rendered > R ? st->layout_rendered : R);
     if (rc) return rc;
     if (stage_fn) stage_fn(stage_ctx, GS4D_RENDER_STAGE_RASTER_DONE);
     // activations: gradients w.r.t. the (deformed) pre-activation scales / rotations and the opacity logits

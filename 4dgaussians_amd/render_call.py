@@ -34,7 +34,7 @@ class RenderDesc(C.Structure):
 
 class RenderState(C.Structure):
     _fields_ = [("arena", FP), ("arena_bytes", C.c_size_t), ("binning", FP), ("binning_bytes", C.c_size_t),
-                ("num_rendered", C.c_int), ("reserved_", C.c_int)]
+                ("num_rendered", C.c_int), ("layout_rendered", C.c_int)]
 
 
 class RenderGrads(C.Structure):

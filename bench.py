@@ -259,6 +259,7 @@ def main():
     L.gs4d_profile_select(None if args.no_stage_events else dominant.encode())
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     stats0 = cabi.forward_stats()
+    spec0 = cabi.speculation_stats()
     step_no[0] = 0                          # the timed region renders views 0, 1, ..., steps - 1 (mod V)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -267,6 +268,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     stats1 = cabi.forward_stats()
+    spec1 = cabi.speculation_stats()
     nviews_timed = args.steps * (VPG if args.mode == "train" else 1)
     view_weight = [sum(1 for i in range(nviews_timed) if i % V == j) / nviews_timed for j in range(V)]
     _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step")
@@ -483,8 +485,10 @@ def main():
                        "collectives_fallback": collectives_fallback,
                        "num_rendered_wait": dict(zip(("mailbox", "copy_sync_fallback"), cabi.mailbox_stats())),
                        # the timed region only: waits that fell back to copy + sync, forwards whose speculative binning
-                       # chunk (previous view's R + 1/8) was too small, plane-gradient point orders ranked / reused
+                       # chunk (largest recent R + 1/8) was too small, forwards whose binning + blend were issued before
+                       # num_rendered had been read / of those, issued again; plane-gradient point orders ranked / reused
                        "timed_region": {"copy_sync_fallback": stats1[1] - stats0[1], "binning_second_allocations": stats1[2] - stats0[2],
+                                        "speculative_forwards": {"issued": spec1[0] - spec0[0], "reissued": spec1[1] - spec0[1]},
                                         "hex_order": hex_order_counts()},
                        "render_path": "staged" if R.STAGED_ONLY else
                                       "gs4d_render_forward / gs4d_render_backward (one call per direction)" +

@@ -148,6 +148,10 @@ void gs4d_mailbox_stats(unsigned long long* fast, unsigned long long* slow);
 /* The same two counters plus *regrow: forwards of the calling thread whose speculative binning chunk (previous
  * num_rendered + 1/8) turned out too small, i.e. that called binning_alloc a second time. */
 void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsigned long long* regrow);
+/* gs4d_render_forward calls of this thread whose binning + blend were issued before num_rendered had been read, and how
+ * many of those had to be re-issued because the count exceeded the speculative capacity (no reference counterpart).
+ * GS4D_NO_SPECULATION=1 switches the speculative launch off. */
+void gs4d_speculation_stats(unsigned long long* issued, unsigned long long* reissued);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; rasterizer_impl.cu:54-66,141-153. `present` is device uint8/bool [P]. */
 int gs4d_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
@@ -397,7 +401,8 @@ typedef struct gs4d_render_state {
     char* binning;
     size_t binning_bytes;
     int num_rendered;
-    int reserved_;
+    int layout_rendered;          /* the count the binning chunk is laid out for (>= num_rendered: the forward issues
+                                     binning and blend before it has read num_rendered, sized for the largest recent count) */
 } gs4d_render_state;
 
 /* out_color [3,H,W], out_depth [1,H,W], radii [P]: written in full.  loss: device [1], required with a target. */

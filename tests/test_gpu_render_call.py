@@ -205,6 +205,50 @@ def test_step_call_equals_autograd_backward():
             assert float((v - 2 * u).abs().max()) <= 2e-6 * float(u.abs().max()) + 1e-12, n
 
 
+def test_speculative_binning_launch_changes_no_result():
+    """gs4d_render_forward issues binning and blend BEFORE it has read num_rendered, sized for the largest of the thread's
+    recent counts + 1/8 (csrc/api.hip); the kernels take the count from device memory and do nothing when it exceeds that
+    capacity, and the host then issues the two stages again with the exact size.  Far view (few instances) nine times,
+    then a near view whose count is several times larger: the near view's launch must overflow, be re-issued, and give
+    the staged path's image and gradients bit for bit; the far views in between run from the speculative launch alone."""
+    R, pc, deform, _, bg, target = small_scene(W=320, H=224, seed=13)
+    syn, cabi = pkg("synthetic"), pkg("_cabi")
+    cam_near = R.Camera(syn.look_at_camera(320, 224, azimuth=0.9, radius=2.6), bg.device, time=0.41)
+    cam_far = R.Camera(syn.look_at_camera(320, 224, azimuth=0.9, radius=20.0), bg.device, time=0.41)
+    names, params = named(pc, deform)
+
+    def step(cam):
+        def f():
+            loss, image, ssp, vis, radii, depth = R.render_with_l1(cam, pc, deform, bg, target)
+            loss.backward()
+            return loss.detach().clone(), image.detach().clone(), radii.clone(), ssp.grad.clone()
+        return f
+
+    far_staged, g_far_staged = run(R, True, step(cam_far), params)
+    near_staged, g_near_staged = run(R, True, step(cam_near), params)
+    n_far, n_near = int((far_staged[2] > 0).sum()), int((near_staged[2] > 0).sum())
+    i0, r0 = cabi.speculation_stats()
+    for _ in range(9):                                           # the capacity follows the last EIGHT counts: forget the near one
+        far, g_far = run(R, False, step(cam_far), params)
+    i1, r1 = cabi.speculation_stats()
+    assert i1 - i0 == 9 and r1 == r0, (i0, r0, i1, r1)          # (the staged calls above left a count to guess from)
+    for x, y in zip(far_staged, far):
+        assert torch.equal(x, y)
+    assert_same(params, names, g_far_staged, g_far)
+    near, g_near = run(R, False, step(cam_near), params)
+    i2, r2 = cabi.speculation_stats()
+    assert i2 - i1 == 1 and r2 - r1 == 1, ("the near view was expected to overflow the far views' capacity", n_far, n_near, i2, r2)
+    for x, y in zip(near_staged, near):
+        assert torch.equal(x, y)
+    assert_same(params, names, g_near_staged, g_near)
+    far, g_far = run(R, False, step(cam_far), params)           # capacity now follows the near view: no re-issue
+    i3, r3 = cabi.speculation_stats()
+    assert i3 - i2 == 1 and r3 == r2
+    for x, y in zip(far_staged, far):
+        assert torch.equal(x, y)
+    assert_same(params, names, g_far_staged, g_far)
+
+
 def test_c2_headline_scene_one_call_equals_staged():
     """BASELINE.json configs[1] as bench.py builds it: the default path of render_with_l1 against the staged path."""
     Wl, R, F = pkg("workload"), pkg("renderer"), pkg("fused")
