@@ -405,7 +405,10 @@ typedef struct gs4d_render_state {
                                      binning and blend before it has read num_rendered, sized for the largest recent count) */
 } gs4d_render_state;
 
-/* out_color [3,H,W], out_depth [1,H,W], radii [P]: written in full.  loss: device [1], required with a target. */
+/* out_color [3,H,W], out_depth [1,H,W], radii [P]: written in full.  loss: device [1], required with a target.
+ * From a thread's second call on, binning and blend are issued before the host has read num_rendered (sized for the
+ * largest of the last eight counts + 1/8, the count itself read on the device) and issued again with the exact size
+ * only if the count exceeded that capacity: same results, the GPU does not idle for the round trip. */
 int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* alloc_ctx,
                         float* out_color, float* out_depth, int* radii, float* loss,
                         gs4d_render_state* state, void* stream);
