@@ -18,6 +18,7 @@ bg = torch.ones(3, device=dev); target = torch.rand(3, 64, 64, device=dev)
 params = list(pc.parameters()) + list(deform.parameters())
 
 WITH_OPT = bool(os.environ.get("HOST_OPT"))        # the optimizer-inclusive iteration (bench field with_optimizer)
+AUTOGRAD = bool(os.environ.get("HOST_AUTOGRAD"))   # render_with_l1 + loss.backward() instead of render_l1_step
 if WITH_OPT:
     reg = importlib.import_module("4dgaussians_amd.scene.regulation"); om = importlib.import_module("4dgaussians_amd.optim")
     opt = om.FusedAdamW([{"params": [pc._xyz], "lr": 0.00016}, {"params": list(deform.get_mlp_parameters()), "lr": 0.00016},
@@ -27,18 +28,14 @@ if WITH_OPT:
 
 
 def step():
-    if not WITH_OPT:                      # the bench's step: render + L1 in one library call per direction
+    # the bench's step: render + L1 in one library call per direction, issued back to back (render_l1_step) or through autograd
+    if AUTOGRAD:
         R.render_with_l1(cam, pc, deform, bg, target)[0].backward()
-        for p in params:
-            p.grad = None
-        return
-    image, *_ = R.render(cam, pc, deform, bg)
-    if WITH_OPT:
-        regul = reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"]
-        (F.l1_loss(image, target) + regul).backward()
-        opt.step()
     else:
-        F.l1_loss(image, target).backward()
+        R.render_l1_step(cam, pc, deform, bg, target)
+    if WITH_OPT:
+        reg.compute_regulation(deform, 0.01, 0.0001, 0.0, 0.0001, detail=False)["total_reg"].backward()
+        opt.step()
     for p in params:
         p.grad = None
 
@@ -50,17 +47,18 @@ for _ in range(200):
     step()
 torch.cuda.synchronize()
 print(f"host-bound step: {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms")
-tf = tb = 0.0
-for _ in range(200):
-    a = time.perf_counter()
-    loss = R.render_with_l1(cam, pc, deform, bg, target)[0]
-    b = time.perf_counter()
-    loss.backward()
-    c = time.perf_counter()
-    for p in params:
-        p.grad = None
-    tf += b - a; tb += c - b
-print(f"forward {tf / 200 * 1e3:.3f} ms, backward {tb / 200 * 1e3:.3f} ms")
+if AUTOGRAD:
+    tf = tb = 0.0
+    for _ in range(200):
+        a = time.perf_counter()
+        loss = R.render_with_l1(cam, pc, deform, bg, target)[0]
+        b = time.perf_counter()
+        loss.backward()
+        c = time.perf_counter()
+        for p in params:
+            p.grad = None
+        tf += b - a; tb += c - b
+    print(f"forward {tf / 200 * 1e3:.3f} ms, backward {tb / 200 * 1e3:.3f} ms")
 prof = cProfile.Profile(); prof.enable()
 for _ in range(200):
     step()
