@@ -38,6 +38,9 @@ __device__ __forceinline__ float fast_exp(float x)
 }
 
 #define FWD_THREADS 128
+#ifndef FWD_PAIR
+#define FWD_PAIR 2          // list entries per trip of the blend loop (0: the one-entry loop, kept for A/B measurements)
+#endif
 static_assert(GS4D_SEG == GS4D_TILE_PIX || 2 * GS4D_SEG == GS4D_TILE_PIX, "checkpoints are taken in front of the batches and, with 128-entry segments, in their middle");
 
 // CKPT: leave the segment checkpoints the backward walks from (BinningState::ckpt / seg_owner, gs4d_internal.h): the
@@ -148,6 +151,62 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
             for (int k = 0; k < GS4D_TILE_PIX / 64; k++) {
                 if (mid_ckpt && 64 * k == GS4D_SEG) checkpoint(base / GS4D_SEG + 1);
                 unsigned long long m = hits[k];
+#if FWD_PAIR
+                // FWD_PAIR entries per trip.  A visit is ONE wave's dependent chain (LDS read -> quadratic form -> exp -> alpha ->
+                // four compare / mask hops between the vector and the scalar unit -> the exit ballot: ~90 instructions that
+                // took ~950 cycles, whatever else ran on the SIMD), but only four instructions of it -- through T -- depend
+                // on the previous entry.  With the next set bits of the mask in one straight-line body the entries'
+                // independent parts overlap; the T-dependent parts run in list order, so every pixel sees exactly the
+                // arithmetic of the one-entry loop (bit-identical images, n_contrib, checkpoints).  A trip that runs out of
+                // set bits repeats its last entry with nobody using it (alpha 0: the identity, as for a skipped entry).
+                while (m != 0ull && !all_done) {
+                    int j[FWD_PAIR];
+                    bool live[FWD_PAIR];
+#pragma unroll
+                    for (int q = 0; q < FWD_PAIR; q++) {
+                        live[q] = m != 0ull;
+                        j[q] = live[q] ? 64 * k + __builtin_ctzll(m) : j[q ? q - 1 : 0];
+                        m &= m - 1;                               // (0 & -1 stays 0)
+                    }
+                    float4 ea[FWD_PAIR], eb[FWD_PAIR];
+                    float2 ec[FWD_PAIR];
+#pragma unroll
+                    for (int q = 0; q < FWD_PAIR; q++) { ea[q] = s_a[j[q]]; eb[q] = s_b[j[q]]; ec[q] = s_c[j[q]]; }
+                    f2 alpha[FWD_PAIR], om[FWD_PAIR];
+                    bool ok0[FWD_PAIR], ok1[FWD_PAIR];
+#pragma unroll
+                    for (int q = 0; q < FWD_PAIR; q++) {          // independent of the other entries of the trip
+                        const f2 dx = ea[q].x - pxf;
+                        const float dy = ea[q].y - pyf;
+                        const f2 power = -0.5f * (ea[q].z * dx * dx + eb[q].x * dy * dy) - ea[q].w * dx * dy;
+                        alpha[q] = f2{fminf(0.99f, eb[q].y * fast_exp<EXACT>(power.x)), fminf(0.99f, eb[q].y * fast_exp<EXACT>(power.y))};
+                        ok0[q] = live[q] && !(power.x > 0.0f) && !(alpha[q].x < (1.0f / 255.0f));
+                        ok1[q] = live[q] && !(power.y > 0.0f) && !(alpha[q].y < (1.0f / 255.0f));
+                        om[q] = 1.0f - alpha[q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < FWD_PAIR; q++) {          // in list order: the only part that depends on T
+                        const f2 test_T = T * om[q];
+                        bool use0 = !done0 && ok0[q], use1 = !done1 && ok1[q];
+                        if (use0 && test_T.x < 0.0001f) { done0 = true; use0 = false; }
+                        if (use1 && test_T.y < 0.0001f) { done1 = true; use1 = false; }
+                        const f2 al = {use0 ? alpha[q].x : 0.f, use1 ? alpha[q].y : 0.f};
+                        const f2 w = al * T;
+                        C0 += eb[q].w * w;
+                        C1 += ec[q].x * w;
+                        C2 += ec[q].y * w;
+                        Dp += eb[q].z * w;
+                        T.x = use0 ? test_T.x : T.x;
+                        T.y = use1 ? test_T.y : T.y;
+                        last0 = use0 ? (uint32_t)(base + j[q] + 1) : last0;
+                        last1 = use1 ? (uint32_t)(base + j[q] + 1) : last1;
+#ifdef GS4D_TIMELINE
+                        tl.visits += live[q] ? 1u : 0u;
+#endif
+                    }
+                    if (__ballot(!done0 || !done1) == 0ull) all_done = true;  // every pixel of this wave is finished
+                }
+#else
                 while (m != 0ull && !all_done) {
                     const int j = 64 * k + __builtin_ctzll(m);
                     m &= m - 1;
@@ -184,6 +243,7 @@ __global__ __launch_bounds__(FWD_THREADS) void blend_forward_kernel(
                     tl.visits++;
 #endif
                 }
+#endif
             }
         }
         __syncthreads();  // the staging arrays are rewritten by the next batch
