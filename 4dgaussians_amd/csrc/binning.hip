@@ -159,22 +159,32 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
     __syncthreads();
 
     const uint32_t total = s_incl[GS4D_PRE_BLOCK - 1];
-    for (uint32_t s = tid; s < total; s += GS4D_PRE_BLOCK) {
-        // first g with s_incl[g] > s
-        int lo = 0, hi = GS4D_PRE_BLOCK - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (s_incl[mid] > s) hi = mid; else lo = mid + 1;
+    // Two slots per trip, each mapped back to its Gaussian by a branch-free eight-step search (first g with
+    // s_incl[g] > slot): a search is a chain of eight dependent LDS reads, two independent chains overlap.
+    for (uint32_t s0 = tid; s0 < total; s0 += 2 * GS4D_PRE_BLOCK) {
+        uint32_t sv[2] = {s0, min(s0 + (uint32_t)GS4D_PRE_BLOCK, total - 1u)};
+        const bool second = s0 + (uint32_t)GS4D_PRE_BLOCK < total;
+        int pos[2] = {0, 0};
+#pragma unroll
+        for (int step = GS4D_PRE_BLOCK / 2; step >= 1; step >>= 1) {
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (s_incl[pos[q] + step - 1] <= sv[q]) pos[q] += step;
         }
-        const int g = lo;
-        const uint32_t excl = g ? s_incl[g - 1] : 0u;
-        const uint32_t k = s - excl;
-        const int w = s_w[g];
-        const int ty = s_y0[g] + (int)(k / (uint32_t)w);
-        const int tx = s_x0[g] + (int)(k % (uint32_t)w);
-        const uint64_t key = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | (uint64_t)s_depth[g];
-        keys[base + s] = key;
-        values[base + s] = (uint32_t)(blockIdx.x * GS4D_PRE_BLOCK + g);
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (q == 1 && !second) break;
+            const int g = pos[q];
+            const uint32_t s = sv[q];
+            const uint32_t excl = g ? s_incl[g - 1] : 0u;
+            const uint32_t k = s - excl;
+            const int w = s_w[g];
+            const int ty = s_y0[g] + (int)(k / (uint32_t)w);
+            const int tx = s_x0[g] + (int)(k % (uint32_t)w);
+            const uint64_t key = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | (uint64_t)s_depth[g];
+            keys[base + s] = key;
+            values[base + s] = (uint32_t)(blockIdx.x * GS4D_PRE_BLOCK + g);
+        }
     }
 }
 
