@@ -45,9 +45,11 @@ __device__ __forceinline__ float3 dnormvdv3(const float3 v, const float3 dv)
 }
 
 // SH backward: writes dL_dsh for the active degree, returns the mean gradient through the view direction.
+// Every read of `sh` comes before the first write of `dL_dsh`: the staged form of geom_backward_kernel hands over ONE
+// LDS row for both (the coefficients in, their gradients out).  The expressions are the reference's, term for term.
 __device__ __forceinline__ float3 sh_backward(int deg, int max_coeffs, const float3 pos, const float3 campos,
                                               const float* __restrict__ sh, const uint8_t* __restrict__ clamped3,
-                                              const float dL_dcolor[3], float* __restrict__ dL_dsh)
+                                              const float dL_dcolor[3], float* dL_dsh)
 {
     const float3 dir_orig = make_float3(pos.x - campos.x, pos.y - campos.y, pos.z - campos.z);
     const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
@@ -56,19 +58,11 @@ __device__ __forceinline__ float3 sh_backward(int deg, int max_coeffs, const flo
     g[0] *= clamped3[0] ? 0 : 1;
     g[1] *= clamped3[1] ? 0 : 1;
     g[2] *= clamped3[2] ? 0 : 1;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
     float ddx[3] = {0, 0, 0}, ddy[3] = {0, 0, 0}, ddz[3] = {0, 0, 0};
-#define GS4D_SETSH(k, wgt)                                        \
-    do {                                                          \
-        const float w_ = (wgt);                                   \
-        dL_dsh[(k) * 3 + 0] = w_ * g[0];                          \
-        dL_dsh[(k) * 3 + 1] = w_ * g[1];                          \
-        dL_dsh[(k) * 3 + 2] = w_ * g[2];                          \
-    } while (0)
-    GS4D_SETSH(0, kSH_C0);
+    // ---- reads
     if (deg > 0) {
-        GS4D_SETSH(1, -kSH_C1 * y);
-        GS4D_SETSH(2, kSH_C1 * z);
-        GS4D_SETSH(3, -kSH_C1 * x);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             ddx[c] = -kSH_C1 * sh[3 * 3 + c];
@@ -76,13 +70,6 @@ __device__ __forceinline__ float3 sh_backward(int deg, int max_coeffs, const flo
             ddz[c] = kSH_C1 * sh[2 * 3 + c];
         }
         if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z;
-            const float xy = x * y, yz = y * z, xz = x * z;
-            GS4D_SETSH(4, kSH_C2[0] * xy);
-            GS4D_SETSH(5, kSH_C2[1] * yz);
-            GS4D_SETSH(6, kSH_C2[2] * (2.f * zz - xx - yy));
-            GS4D_SETSH(7, kSH_C2[3] * xz);
-            GS4D_SETSH(8, kSH_C2[4] * (xx - yy));
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const float s4 = sh[4 * 3 + c], s5 = sh[5 * 3 + c], s6 = sh[6 * 3 + c], s7 = sh[7 * 3 + c],
@@ -92,13 +79,6 @@ __device__ __forceinline__ float3 sh_backward(int deg, int max_coeffs, const flo
                 ddz[c] += kSH_C2[1] * y * s5 + kSH_C2[2] * 2.f * 2.f * z * s6 + kSH_C2[3] * x * s7;
             }
             if (deg > 2) {
-                GS4D_SETSH(9, kSH_C3[0] * y * (3.f * xx - yy));
-                GS4D_SETSH(10, kSH_C3[1] * xy * z);
-                GS4D_SETSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy));
-                GS4D_SETSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                GS4D_SETSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy));
-                GS4D_SETSH(14, kSH_C3[5] * z * (xx - yy));
-                GS4D_SETSH(15, kSH_C3[6] * x * (xx - 3.f * yy));
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     const float s9 = sh[9 * 3 + c], s10 = sh[10 * 3 + c], s11 = sh[11 * 3 + c], s12 = sh[12 * 3 + c];
@@ -117,6 +97,36 @@ __device__ __forceinline__ float3 sh_backward(int deg, int max_coeffs, const flo
             }
         }
     }
+    // ---- writes
+#define GS4D_SETSH(k, wgt)                                        \
+    do {                                                          \
+        const float w_ = (wgt);                                   \
+        dL_dsh[(k) * 3 + 0] = w_ * g[0];                          \
+        dL_dsh[(k) * 3 + 1] = w_ * g[1];                          \
+        dL_dsh[(k) * 3 + 2] = w_ * g[2];                          \
+    } while (0)
+    GS4D_SETSH(0, kSH_C0);
+    if (deg > 0) {
+        GS4D_SETSH(1, -kSH_C1 * y);
+        GS4D_SETSH(2, kSH_C1 * z);
+        GS4D_SETSH(3, -kSH_C1 * x);
+        if (deg > 1) {
+            GS4D_SETSH(4, kSH_C2[0] * xy);
+            GS4D_SETSH(5, kSH_C2[1] * yz);
+            GS4D_SETSH(6, kSH_C2[2] * (2.f * zz - xx - yy));
+            GS4D_SETSH(7, kSH_C2[3] * xz);
+            GS4D_SETSH(8, kSH_C2[4] * (xx - yy));
+            if (deg > 2) {
+                GS4D_SETSH(9, kSH_C3[0] * y * (3.f * xx - yy));
+                GS4D_SETSH(10, kSH_C3[1] * xy * z);
+                GS4D_SETSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy));
+                GS4D_SETSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                GS4D_SETSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy));
+                GS4D_SETSH(14, kSH_C3[5] * z * (xx - yy));
+                GS4D_SETSH(15, kSH_C3[6] * x * (xx - 3.f * yy));
+            }
+        }
+    }
 #undef GS4D_SETSH
     const float3 dL_ddir = make_float3(ddx[0] * g[0] + ddx[1] * g[1] + ddx[2] * g[2],
                                        ddy[0] * g[0] + ddy[1] * g[1] + ddy[2] * g[2],
@@ -125,7 +135,8 @@ __device__ __forceinline__ float3 sh_backward(int deg, int max_coeffs, const flo
 }
 
 // Everything after the row sums are known.  r[0..2] colour, r[3] depth, r[4..5] mean2D, r[6..8] conic, r[9] opacity.
-__device__ void gaussian_backward(const GeomBwdArgs& A, int idx, const float r[NQ])
+// sh_row / dsh_row: this Gaussian's coefficients and where their gradients go (global rows, or one LDS row for both)
+__device__ __forceinline__ void gaussian_backward(const GeomBwdArgs& A, int idx, const float r[NQ], const float* sh_row, float* dsh_row)
 {
     const float* view = A.view;
     const float* proj = A.proj;
@@ -230,8 +241,7 @@ __device__ void gaussian_backward(const GeomBwdArgs& A, int idx, const float r[N
 
     if (A.shs != nullptr) {
         const float3 cp = make_float3(A.campos[0], A.campos[1], A.campos[2]);
-        const float3 d3 = sh_backward(A.D, A.M, m, cp, A.shs + (size_t)idx * A.M * 3, A.clamped + 3 * (size_t)idx, r,
-                                      A.dL_dsh + (size_t)idx * A.M * 3);
+        const float3 d3 = sh_backward(A.D, A.M, m, cp, sh_row, A.clamped + 3 * (size_t)idx, r, dsh_row);
         dmean.x += d3.x; dmean.y += d3.y; dmean.z += d3.z;
     }
     A.dL_dmean3D[3 * idx + 0] = dmean.x;
@@ -276,56 +286,96 @@ __device__ void gaussian_backward(const GeomBwdArgs& A, int idx, const float r[N
     }
 }
 
-__global__ __launch_bounds__(256) void geom_backward_kernel(GeomBwdArgs A)
+// STAGED (16 SH coefficients per Gaussian, 16-byte aligned arrays): a lane's 48 coefficient reads and 48 gradient writes
+// are 192 bytes apart from its neighbour's, i.e. every one of those 96 instructions touched 64 different cache lines and
+// the kernel sat on the texture-address path (17 of its 30 us at C2 by that count).  The workgroup now copies its
+// Gaussians' coefficient rows into LDS with coalesced float4 loads (row pitch 49 words: conflict-free for equal
+// columns), every lane works on its own LDS row -- gradients overwrite the coefficients, sh_backward reads before it
+// writes -- and the rows leave as coalesced float4 stores.  Rows of culled and deferred Gaussians leave as zeros (the
+// deferred ones are filled in by geom_backward_big_kernel afterwards), so dL_dsh needs no clearing by the caller.
+#define GEOM_BLOCK 128
+#define GEOM_SH_PITCH 49
+template <bool STAGED>
+__global__ __launch_bounds__(GEOM_BLOCK) void geom_backward_kernel(GeomBwdArgs A)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= A.P) return;
-    // requested together (under the tests below they were three memory latencies in a row)
-    const int radius = A.radii[idx];
-    const uint32_t cnt = A.tiles_touched[idx];
-    const uint32_t end = A.point_offsets[idx];
-    if (!(radius > 0)) {
-        // dL_dmean2D is written in full (the caller may hand over uninitialised memory for it, see include/gs4d.h)
-        A.dL_dmean2D[3 * idx + 0] = 0.f; A.dL_dmean2D[3 * idx + 1] = 0.f; A.dL_dmean2D[3 * idx + 2] = 0.f;
-        return;
+    extern __shared__ float s_sh[];                       // STAGED: [GEOM_BLOCK][GEOM_SH_PITCH]
+    const int idx = blockIdx.x * GEOM_BLOCK + threadIdx.x;
+    const int base = blockIdx.x * GEOM_BLOCK;
+    const int nrows = min(GEOM_BLOCK, A.P - base);
+    if (STAGED) {
+        const float4* __restrict__ src = reinterpret_cast<const float4*>(A.shs + (size_t)base * 48);
+        for (int i = threadIdx.x; i < nrows * 12; i += GEOM_BLOCK) {
+            const float4 v = src[i];
+            float* d = s_sh + (i / 12) * GEOM_SH_PITCH + (i % 12) * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
     }
-    if (cnt > GS4D_BIG_ROWS) {
-        const uint32_t slot = atomicAdd(A.big_count, 1u);
-        A.big_list[slot] = (uint32_t)idx;
-        return;
-    }
-    const uint32_t first = end - cnt;
-    // The rows are summed in DOUBLE: the kernel waits on memory ~90 % of the time, so the wider adds are free, and the
-    // sums then carry only the rounding of the per-tile partials (the reference's float atomics add in arbitrary order;
-    // the oracle sums in double) -- dL_dscales / dL_drotations, derived through a cancelling chain, meet 1e-4 this way.
-    double r[NQ];
+    float* my_row = s_sh + threadIdx.x * GEOM_SH_PITCH;
+    bool wrote_row = false;
+    if (idx < A.P) {
+        // requested together (under the tests below they were three memory latencies in a row)
+        const int radius = A.radii[idx];
+        const uint32_t cnt = A.tiles_touched[idx];
+        const uint32_t end = A.point_offsets[idx];
+        if (!(radius > 0)) {
+            // dL_dmean2D is written in full (the caller may hand over uninitialised memory for it, see include/gs4d.h)
+            A.dL_dmean2D[3 * idx + 0] = 0.f; A.dL_dmean2D[3 * idx + 1] = 0.f; A.dL_dmean2D[3 * idx + 2] = 0.f;
+        } else if (cnt > GS4D_BIG_ROWS) {
+            const uint32_t slot = atomicAdd(A.big_count, 1u);
+            A.big_list[slot] = (uint32_t)idx;
+        } else {
+            const uint32_t first = end - cnt;
+            // The rows are summed in DOUBLE: the kernel waits on memory most of the time, so the wider adds are free, and the
+            // sums then carry only the rounding of the per-tile partials (the reference's float atomics add in arbitrary order;
+            // the oracle sums in double) -- dL_dscales / dL_drotations, derived through a cancelling chain, meet 1e-4 this way.
+            double r[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; q++) r[q] = 0.0;
-    const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
-    // The Gaussian's rows are contiguous (blend_backward_kernel writes a row at its emission slot): four rows are
-    // requested together, summed in the same order as one by one.
-    uint32_t s = first;
-    for (; s + 4 <= end; s += 4) {
-        float4 a[4], b[4], c[4];
+            for (int q = 0; q < NQ; q++) r[q] = 0.0;
+            const float4* rows = reinterpret_cast<const float4*>(A.inst_grad);
+            // The Gaussian's rows are contiguous (blend_backward_kernel writes a row at its emission slot): four rows are
+            // requested together, summed in the same order as one by one.
+            uint32_t s = first;
+            for (; s + 4 <= end; s += 4) {
+                float4 a[4], b[4], c[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { a[u] = rows[(size_t)(s + u) * 3 + 0]; b[u] = rows[(size_t)(s + u) * 3 + 1]; c[u] = rows[(size_t)(s + u) * 3 + 2]; }
+                for (int u = 0; u < 4; u++) { a[u] = rows[(size_t)(s + u) * 3 + 0]; b[u] = rows[(size_t)(s + u) * 3 + 1]; c[u] = rows[(size_t)(s + u) * 3 + 2]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            r[0] += a[u].x; r[1] += a[u].y; r[2] += a[u].z; r[3] += a[u].w;
-            r[4] += b[u].x; r[5] += b[u].y; r[6] += b[u].z; r[7] += b[u].w;
-            r[8] += c[u].x; r[9] += c[u].y;
+                for (int u = 0; u < 4; u++) {
+                    r[0] += a[u].x; r[1] += a[u].y; r[2] += a[u].z; r[3] += a[u].w;
+                    r[4] += b[u].x; r[5] += b[u].y; r[6] += b[u].z; r[7] += b[u].w;
+                    r[8] += c[u].x; r[9] += c[u].y;
+                }
+            }
+            for (; s < end; s++) {
+                const float4 a = rows[(size_t)s * 3 + 0], b = rows[(size_t)s * 3 + 1], c = rows[(size_t)s * 3 + 2];
+                r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
+                r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
+                r[8] += c.x; r[9] += c.y;
+            }
+            float rf[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; q++) rf[q] = (float)r[q];
+            if (STAGED) {
+                gaussian_backward(A, idx, rf, my_row, my_row);
+                for (int k = (A.D + 1) * (A.D + 1) * 3; k < 48; k++) my_row[k] = 0.f;     // coefficients above the active degree
+                wrote_row = true;
+            } else {
+                gaussian_backward(A, idx, rf, A.shs ? A.shs + (size_t)idx * A.M * 3 : nullptr,
+                                  A.dL_dsh ? A.dL_dsh + (size_t)idx * A.M * 3 : nullptr);
+            }
         }
     }
-    for (; s < end; s++) {
-        const float4 a = rows[(size_t)s * 3 + 0], b = rows[(size_t)s * 3 + 1], c = rows[(size_t)s * 3 + 2];
-        r[0] += a.x; r[1] += a.y; r[2] += a.z; r[3] += a.w;
-        r[4] += b.x; r[5] += b.y; r[6] += b.z; r[7] += b.w;
-        r[8] += c.x; r[9] += c.y;
+    if (STAGED) {
+        if (!wrote_row)
+            for (int k = 0; k < 48; k++) my_row[k] = 0.f;
+        __syncthreads();
+        float4* __restrict__ dst = reinterpret_cast<float4*>(A.dL_dsh + (size_t)base * 48);
+        for (int i = threadIdx.x; i < nrows * 12; i += GEOM_BLOCK) {
+            const float* d = s_sh + (i / 12) * GEOM_SH_PITCH + (i % 12) * 4;
+            dst[i] = make_float4(d[0], d[1], d[2], d[3]);
+        }
     }
-    float rf[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; q++) rf[q] = (float)r[q];
-    gaussian_backward(A, idx, rf);
 }
 
 // One WAVE per deferred Gaussian (four per workgroup, no workgroup barriers): lane t sums rows first+t, first+t+64, ...,
@@ -356,11 +406,19 @@ __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
         float rf[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) rf[q] = (float)r[q];
-        if (lane == 0) gaussian_backward(A, idx, rf);
+        if (lane == 0)
+            gaussian_backward(A, idx, rf, A.shs ? A.shs + (size_t)idx * A.M * 3 : nullptr, A.dL_dsh ? A.dL_dsh + (size_t)idx * A.M * 3 : nullptr);
     }
 }
 
 }  // namespace
+
+// true: the launch below writes every element of dL_dsh (zeros for culled Gaussians and inactive degrees), the caller need
+// not clear it -- except when nothing was rendered, when no kernel runs at all
+bool gs4d_geom_backward_fills_dsh(int M, const float* shs, const float* dL_dsh)
+{
+    return M == 16 && shs && dL_dsh && !((uintptr_t)shs & 15) && !((uintptr_t)dL_dsh & 15);
+}
 
 int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const float* means3D, const int* radii,
                               const float* shs, const float* scales, const float* rotations, float scale_modifier,
@@ -388,7 +446,11 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
     // the counter was cleared by blend_backward_kernel (api.hip)
     A.big_count = gs4d_backward_big_count(inst_grad, R);
     A.big_list = (uint32_t*)((char*)A.big_count + 256);
-    hipLaunchKernelGGL(geom_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, A);
+    if (gs4d_geom_backward_fills_dsh(M, shs, dL_dsh))
+        hipLaunchKernelGGL(geom_backward_kernel<true>, dim3((P + GEOM_BLOCK - 1) / GEOM_BLOCK), dim3(GEOM_BLOCK),
+                           sizeof(float) * GEOM_BLOCK * GEOM_SH_PITCH, s, A);
+    else
+        hipLaunchKernelGGL(geom_backward_kernel<false>, dim3((P + GEOM_BLOCK - 1) / GEOM_BLOCK), dim3(GEOM_BLOCK), 0, s, A);
     GS4D_LAUNCH_CHECK("geom_backward", debug, s);
     hipLaunchKernelGGL(geom_backward_big_kernel, dim3(1024), dim3(256), 0, s, A);
     GS4D_LAUNCH_CHECK("geom_backward_big", debug, s);

@@ -180,6 +180,7 @@ static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
 {
     return (uint32_t*)((char*)inst_grad + gs4d_align_up((size_t)R * GS4D_GRAD_ROW * sizeof(float), 256));
 }
+bool gs4d_geom_backward_fills_dsh(int M, const float* shs, const float* dL_dsh);     // csrc/geom_bwd.hip
 int gs4d_launch_blend_forward(int W, int H, const GeomState& g, const BinningState& b, ImageState& im,
                               const float* features, const float* bg, float* out_color, float* out_depth, int checkpoints,
                               int debug, hipStream_t s);

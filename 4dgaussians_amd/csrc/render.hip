@@ -228,7 +228,10 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
 
     // what the rasterizer backward accumulates into / leaves untouched for culled Gaussians starts at zero
     GS4D_HIP_CHECK(hipMemsetAsync(b.zero_begin, 0, (size_t)((char*)b.zero_end - (char*)b.zero_begin), s));
-    GS4D_HIP_CHECK(hipMemsetAsync(g->d_shs, 0, sizeof(float) * (size_t)r->M * 3 * P, s));
+    const float* shs_in = r->deform ? f.shs : r->shs;
+    // the per-Gaussian backward writes every element of d_shs itself when its staged form applies (csrc/geom_bwd.hip)
+    if (R == 0 || !gs4d_geom_backward_fills_dsh(r->M, shs_in, g->d_shs))
+        GS4D_HIP_CHECK(hipMemsetAsync(g->d_shs, 0, sizeof(float) * (size_t)r->M * 3 * P, s));
     float* dL_dmean3D = r->deform ? b.dL_dmean3D : g->d_xyz;
     if (!r->deform) GS4D_HIP_CHECK(hipMemsetAsync(g->d_xyz, 0, sizeof(float) * 3 * P, s));
     if (R == 0) GS4D_HIP_CHECK(hipMemsetAsync(g->dL_dmeans2D, 0, sizeof(float) * 3 * P, s));
