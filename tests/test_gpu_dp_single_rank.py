@@ -14,8 +14,9 @@ from oracle import deformation_ref as R
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("step_call", [False, True], ids=["autograd", "render_l1_step"])
 @pytest.mark.parametrize("direct", [False, True], ids=["torch_collectives", "rccl_direct"])
-def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path, direct):
+def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path, direct, step_call):
     RD, F, syn, par = pkg("renderer"), pkg("fused"), pkg("synthetic"), pkg("parallel")
     cfg = R.DeformConfig(plane_channels=16, resolution=[16, 16, 16, 8], multires=[1, 2])
     torch.manual_seed(5)
@@ -49,8 +50,11 @@ def test_hooks_bucket_and_rccl_in_a_world_of_one(tmp_path, direct):
         shs_hook = lambda g: started.append(bucket.early_reduce(pc._features, g))
         for step in range(3):
             del started[:]
-            image, *_ = RD.render(cam, pc, deform, bg, shs_grad_hook=shs_hook)
-            F.l1_loss(image, target).backward()
+            if step_call:                                          # the bench's form: both library calls back to back, no autograd graph
+                RD.render_l1_step(cam, pc, deform, bg, target, shs_grad_hook=shs_hook)
+            else:
+                image, *_ = RD.render(cam, pc, deform, bg, shs_grad_hook=shs_hook)
+                F.l1_loss(image, target).backward()
             assert started == [step > 0, step > 0]                 # SH hook first, then the data phase
             bucket.all_reduce()
             if step == 1 and direct:                               # the exchange really ran: poison check through a sum
