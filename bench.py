@@ -425,7 +425,7 @@ def main():
         L2_PEAK_GBS = 34500.0                                                        # MI355X_MICROARCH.md: aggregate L2
         PD = P * (VPG if args.mode == "train" else 1)                                # rows of one deformation launch
         spec = {  # stage -> (bound, units of work per launch, unit, peak, kernel name prefix in the PMC files, what)
-            "hexplane_forward": ("l2-gather", PD * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_forward_kernel",
+            "hexplane_forward": ("l2-gather", PD * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_forward_shared_kernel",
                                  "levels*6*4*C*4 B gathered + L*C*4 B written per Gaussian (SURVEY upper bound: served by L2 / Infinity Cache, the planes themselves are read from HBM once)"),
             "mlp_forward": ("mfma", PD * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_forward_kernel", "2*sum(in*out) FLOP per Gaussian, exact-f32 MFMA"),
             "preprocess": ("hbm", 311.0 * P, "GB/s", HBM_PEAK_GBS, "preprocess_kernel", "311 B per Gaussian"),
@@ -435,7 +435,7 @@ def main():
             "geom_backward": ("hbm", 567.0 * P + 48.0 * Rn, "GB/s", HBM_PEAK_GBS, "geom_backward_kernel", "567 B per Gaussian + 48 B per instance row"),
             "mlp_backward": ("mfma", PD * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "heads_backward_kernel", "input gradients of every Linear: the forward's FLOP count"),
             "weight_grads": ("mfma", PD * mlp_flops, "TFLOP/s", FP32_PEAK_TFLOPS, "dw_partial_kernel", "weight gradients of every Linear: the forward's FLOP count"),
-            "hexplane_backward": ("l2-gather", 2.0 * PD * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_backward_point_kernel", "twice the forward's gather figure (read the corners, add the gradients)"),
+            "hexplane_backward": ("l2-gather", 2.0 * PD * gather_bytes, "GB/s", L2_PEAK_GBS, "hexplane_backward_point_shared_kernel", "twice the forward's gather figure (read the corners, add the gradients)"),
         }
         DEFORM_STAGES = ("hexplane_forward", "mlp_forward", "activate_forward", "activate_backward", "mlp_backward", "hexplane_backward", "weight_grads")
         launches = lambda st: 1 if (st in DEFORM_STAGES or args.mode != "train") else VPG
