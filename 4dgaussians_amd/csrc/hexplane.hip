@@ -210,7 +210,9 @@ __device__ __forceinline__ SixSamples six_samples(const PlaneTable& T, int l, in
 //      rows only when the cell changes: ~6x (fine level) to ~25x (coarse level, time planes) fewer atomic
 //      rows.  Correctness never depends on the grouping (a flush happens on every cell change), so per-point
 //      timestamps, clustered scenes and non-power-of-two multires just change how often it flushes.
+#ifndef HEX_RUN
 #define HEX_RUN 32
+#endif
 // plane i of a level is served by sort kSortOf[i]; its (A, B) coordinates are fields kSelA/kSelB of the sorted
 // record (p, a, b, t'): S0 = (x, y), S1 = (y, z), S2 = (x, z)
 __device__ __constant__ const int kSortOf[6] = {0, 2, 0, 1, 1, 2};
@@ -511,7 +513,9 @@ __global__ __launch_bounds__(256) void hexplane_rec_from_order_kernel(int P, int
 // memory atomics they saved), so a cell spanning the whole workgroup -- every time plane, whose points share
 // two texel rows -- reaches memory once per workgroup.  Same-line memory-side atomics serialise at ~0.5 us
 // each: the 128 hot rows of the coarse time planes alone cost 57 us when every run flushed to memory.
-#define HEX_RPW 4
+#ifndef HEX_RPW
+#define HEX_RPW 1          // steps per group: 4 -> 1 in round 3 (the walk of a group is a serial chain: 47 us at ANY point count below 100 k with four steps; the extra end-of-group merges cost less than the shorter chain saves: 135 -> 127 us at C2, neutral at C5)
+#endif
 #define HEX_GATHER 16
 template <int lanes_shift>
 __global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, int C, int L, PlaneTable T,
