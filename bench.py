@@ -197,6 +197,13 @@ def main():
     if dp and dp_hooks == "all":
         deform.deformation_net.data_grad_hook = data_hook
 
+    def binning_bytes_per_instance(n_rendered):
+        import ctypes as C
+        Rn = max(int(n_rendered), 1)
+        L.gs4d_binning_bytes_forward_only.restype = C.c_size_t
+        return {"train": round(L.gs4d_binning_bytes(C.c_int(Rn)) / Rn, 1),
+                "forward_only": round(L.gs4d_binning_bytes_forward_only(C.c_int(Rn)) / Rn, 1)}
+
     VPG = max(1, args.views_per_gpu)
     FUSED_STEP = not args.autograd_step and not R.STAGED_ONLY
 
@@ -490,6 +497,9 @@ def main():
                        "timed_region": {"copy_sync_fallback": stats1[1] - stats0[1], "binning_second_allocations": stats1[2] - stats0[2],
                                         "speculative_forwards": {"issued": spec1[0] - spec0[0], "reissued": spec1[1] - spec0[1]},
                                         "hex_order": hex_order_counts()},
+                       # memory of the per-view binning state (keys, values, sort buffers, histograms + the blend's segment
+                       # checkpoints that only a training forward reserves), per rendered instance
+                       "binning_bytes_per_instance": binning_bytes_per_instance(Rn),
                        "render_path": "staged" if R.STAGED_ONLY else
                                       "gs4d_render_forward / gs4d_render_backward (one call per direction)" +
                                       (", issued back to back by renderer.render_l1_step" if FUSED_STEP and VPG == 1 else
