@@ -213,21 +213,27 @@ def render(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module], bg_colo
 
 
 def render_batch(cams, pc: GaussianParams, deform: Optional[nn.Module], bg_color: torch.Tensor,
-                 scaling_modifier: float = 1.0, stage: str = "fine"):
-    """Several views of one step on one GPU -> [(image, screenspace_points, visibility_filter, radii, depth), ...].
+                 scaling_modifier: float = 1.0, stage: str = "fine", targets=None):
+    """Several views of one step on one GPU -> [(image, screenspace_points, visibility_filter, radii, depth), ...], or,
+    with `targets` (one ground-truth image per view), [(loss, image, screenspace_points, visibility_filter, radii,
+    depth), ...] with every view's L1 loss computed inside its library call as render_with_l1 does.
 
     The reference renders the views of a batch one after the other (train.py:169-189), each with its own deformation
     query; BASELINE.json's multi-GPU configurations put 2-8 views of a step on every rank.  Here the deformation field
     is queried ONCE for all B views -- B * P rows with a per-row timestamp, which gs4d_deform_forward takes anyway --
     and so is its backward: the weight-gradient products, the plane-gradient pipeline and every launch of the field
     run once per step instead of once per view, and autograd adds up the views' parameter gradients in one reduction
-    per tensor.  The rasterizer then runs once per view on its slice of the rows.  Results per view equal render()'s
-    (identical images; gradients up to the order in which the views are summed)."""
+    per tensor.  Each view's slice of the rows then goes through the composite call without a deformation field
+    (activations + rasterizer [+ L1] in one library call per direction, binning issued before num_rendered has been
+    read: render_call.py); the per-stage path is the fallback.  Results per view equal render()'s (identical images;
+    gradients up to the order in which the views are summed)."""
     B = len(cams)
     if B == 0:
         return []
     if "coarse" in stage or deform is None or B == 1:
-        return [render(c, pc, deform, bg_color, scaling_modifier, stage) for c in cams]
+        if targets is None:
+            return [render(c, pc, deform, bg_color, scaling_modifier, stage) for c in cams]
+        return [render_with_l1(c, pc, deform, bg_color, t, scaling_modifier, stage) for c, t in zip(cams, targets)]
     shs = pc._features if hasattr(pc, "_features") else pc.get_features
     n, dev = pc._xyz.shape[0], pc._xyz.device
     cols = [c.time_force_columns(n, dev) if hasattr(c, "time_force_columns") else
@@ -237,21 +243,39 @@ def render_batch(cams, pc: GaussianParams, deform: Optional[nn.Module], bg_color
     tile = lambda t: t.expand(B, *t.shape).reshape(B * n, *t.shape[1:])        # B copies of the rows, one kernel
     m3, sc, rot, op, sh = deform.forward_dynamic(tile(pc._xyz), tile(pc._scaling), tile(pc._rotation), tile(pc._opacity),
                                                  tile(shs), times, forces, None)
-    sc, rot, op = activate(sc, rot, op)
-    per_view = [t.view(B, n, *t.shape[1:]).unbind(0) for t in (m3, sc, rot, op, sh)]
-    out = []
+    raw_view = [t.view(B, n, *t.shape[1:]).unbind(0) for t in (m3, sc, rot, op, sh)]
+    grad = torch.is_grad_enabled()
+    new_ssp = lambda: (_shared_zeros(tuple(pc._xyz.shape), dev).detach().requires_grad_(True) if grad else torch.empty_like(pc._xyz))
+    out, staged = [], None
     for b, cam in enumerate(cams):
-        screenspace_points = (_shared_zeros(tuple(pc._xyz.shape), dev).detach().requires_grad_(True) if torch.is_grad_enabled()
-                              else torch.empty_like(pc._xyz))
-        settings = GaussianRasterizationSettings(
-            image_height=int(cam.image_height), image_width=int(cam.image_width),
-            tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
-            scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
-            sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
-        image, radii, depth = GaussianRasterizer(raster_settings=settings)(
-            means3D=per_view[0][b], means2D=screenspace_points, shs=per_view[4][b], colors_precomp=None,
-            opacities=per_view[3][b], scales=per_view[1][b], rotations=per_view[2][b], cov3D_precomp=None)
-        out.append((image, screenspace_points, radii > 0, radii, depth))
+        screenspace_points = new_ssp()
+        target = None if targets is None else targets[b]
+        res = None
+        if not STAGED_ONLY and isinstance(bg_color, torch.Tensor) and sh.dim() == 3 and sh.shape[1] == 16:
+            call = RenderCall(cam, bg_color, scaling_modifier, pc.active_sh_degree, False, None, None, None, target, None)
+            tensors = (raw_view[0][b], raw_view[1][b], raw_view[2][b], raw_view[3][b], raw_view[4][b])
+            if call.applicable(tensors):
+                res = render_call(call, tensors[0], tensors[1], tensors[2], tensors[3], tensors[4], screenspace_points)
+        if res is not None:
+            image, radii, depth, loss = res
+        else:
+            if staged is None:                              # one batched activation for the views that take the per-stage path
+                a_sc, a_rot, a_op = activate(sc, rot, op)
+                staged = [t.view(B, n, *t.shape[1:]).unbind(0) for t in (a_sc, a_rot, a_op)]
+            settings = GaussianRasterizationSettings(
+                image_height=int(cam.image_height), image_width=int(cam.image_width),
+                tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,
+                scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                sh_degree=pc.active_sh_degree, campos=cam.camera_center, prefiltered=False, debug=False)
+            image, radii, depth = GaussianRasterizer(raster_settings=settings)(
+                means3D=raw_view[0][b], means2D=screenspace_points, shs=raw_view[4][b], colors_precomp=None,
+                opacities=staged[2][b], scales=staged[0][b], rotations=staged[1][b], cov3D_precomp=None)
+            loss = None
+            if target is not None:
+                from .fused import l1_loss
+                loss = l1_loss(image, target)
+        view = (image, screenspace_points, radii > 0, radii, depth)
+        out.append(view if targets is None else (loss,) + view)
     return out
 
 

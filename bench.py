@@ -209,10 +209,10 @@ def main():
 
     def batch_step():
         vs = [next_view() for _ in range(VPG)]
-        outs = R.render_batch([v.cam for v in vs], pc, deform, bg)
-        loss = F.l1_loss(outs[0][0], vs[0].target)
-        for o, v in zip(outs[1:], vs[1:]):
-            loss = loss + F.l1_loss(o[0], v.target)
+        outs = R.render_batch([v.cam for v in vs], pc, deform, bg, targets=[v.target for v in vs])
+        loss = outs[0][0]
+        for o in outs[1:]:
+            loss = loss + o[0]
         (loss / (VPG * world)).backward()                 # mean over the global batch of views
         if dp:
             bucket.all_reduce()

@@ -296,12 +296,20 @@ def test_render_batch_equals_per_view_renders():
         sum(F.l1_loss(o[0], t) for o, t in zip(outs, targets)).backward()
         return [(o[0].detach().clone(), o[3].clone(), o[4].detach().clone(), o[1].grad.clone()) for o in outs]
 
+    def batched_with_targets():                     # every view's L1 inside its library call
+        outs = R.render_batch(cams, pc, deform, bg, targets=targets)
+        sum(o[0] for o in outs).backward()
+        for o, t in zip(outs, targets):
+            assert torch.equal(o[0].detach(), F.l1_loss(o[1].detach(), t))
+        return [(o[1].detach().clone(), o[4].clone(), o[5].detach().clone(), o[2].grad.clone()) for o in outs]
+
     a, ga = run(R, False, one_by_one, params)
-    b, gb = run(R, False, batched, params)
-    for va, vb in zip(a, b):
-        for x, y in zip(va, vb):
-            assert torch.equal(x, y)
-    for n, x, y in zip(names, ga, gb):
-        assert (x is None) == (y is None), n
-        if x is not None:
-            assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()) + 1e-12, (n, float((x - y).abs().max()), float(x.abs().max()))
+    for fn, staged in ((batched, False), (batched_with_targets, False), (batched, True), (batched_with_targets, True)):
+        b, gb = run(R, staged, fn, params)          # staged: the per-stage fallback of render_batch
+        for va, vb in zip(a, b):
+            for x, y in zip(va, vb):
+                assert torch.equal(x, y)
+        for n, x, y in zip(names, ga, gb):
+            assert (x is None) == (y is None), n
+            if x is not None:
+                assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max()) + 1e-12, (n, float((x - y).abs().max()), float(x.abs().max()))
