@@ -69,6 +69,14 @@ def speculation_stats():
     return tuple(x.value for x in v)
 
 
+def binning_stats():
+    """(direct, passes): forwards of this thread binned by direct placement / by the radix passes on the tile bits
+    (include/gs4d.h: gs4d_binning_stats)."""
+    v = [C.c_ulonglong(0) for _ in range(2)]
+    lib().gs4d_binning_stats(*(C.byref(x) for x in v))
+    return tuple(x.value for x in v)
+
+
 def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().gs4d_last_error().decode(errors="replace")

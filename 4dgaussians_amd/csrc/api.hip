@@ -13,7 +13,8 @@
 #include <time.h>
 #include "gs4d_internal.h"
 
-int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t seq, int debug, hipStream_t s);
+int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t seq, int debug, hipStream_t s,
+                     uint32_t* tile_cursor = nullptr, uint32_t* tile_base = nullptr, int ntiles = 0);
 
 static thread_local char g_err[512] = "";
 
@@ -28,6 +29,8 @@ struct ThreadState {
     size_t last_R = 0;
     size_t recent_R[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last eight counts: the speculative launch sizes for their maximum
     unsigned recent_i = 0;
+    bool direct_next = false;                   // the last forward found the rows spatially coherent: bin by direct placement
+    unsigned long long binned_direct = 0, binned_passes = 0;
     unsigned long long speculated = 0, respun = 0;  // forwards whose binning + blend were issued before the count was read / of those, re-issued
     unsigned long long fast = 0, slow = 0;      // how often the count arrived through the mailbox / the copy + sync path
     unsigned long long regrow = 0;              // forwards whose speculative binning chunk was too small (second allocation)
@@ -187,6 +190,7 @@ GeomState GeomState::from_chunk(char*& chunk, size_t P)
     gs4d_obtain(chunk, g.block_sums, nblk);
     gs4d_obtain(chunk, g.block_offsets, nblk);
     gs4d_obtain(chunk, g.counters, 64);
+    gs4d_obtain(chunk, g.block_area, nblk);
     return g;
 }
 
@@ -204,6 +208,8 @@ ImageState ImageState::from_chunk(char*& chunk, size_t npix, size_t ntiles)
     gs4d_obtain(chunk, im.n_contrib, npix);
     gs4d_obtain(chunk, im.ranges, ntiles);
     gs4d_obtain(chunk, im.tile_max_contrib, ntiles);
+    gs4d_obtain(chunk, im.tile_cursor, ntiles * GS4D_TILE_CURSOR_STRIDE);
+    gs4d_obtain(chunk, im.tile_base, ntiles + 1);
     return im;
 }
 
@@ -250,6 +256,12 @@ bool gs4d_sort_tile_first()
     return v;
 }
 
+int gs4d_sort_direct_forced()
+{
+    static const int v = [] { const char* e = getenv("GS4D_SORT"); return !e || !e[0] ? -1 : (e[0] == 'd' ? 1 : 0); }();
+    return v;
+}
+
 uint32_t gs4d_sort_segment_cap()
 {
     // GS4D_SORT_SEGMENT_CAP (tests): lists longer than this take the chunked global path; at most 2048 (SEG_CAP of binning.hip)
@@ -287,7 +299,7 @@ extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
 unsigned long long gs4d_debug_alloc_calls(void) { return g_alloc_calls.load(std::memory_order_relaxed); }
-int gs4d_abi_version(void) { return 11; }
+int gs4d_abi_version(void) { return 12; }
 
 void gs4d_thread_state_release(void)
 {
@@ -306,6 +318,12 @@ void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsi
 {
     gs4d_mailbox_stats(fast, slow);
     if (regrow) *regrow = t_state.regrow;
+}
+
+void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes)
+{
+    if (direct) *direct = t_state.binned_direct;
+    if (passes) *passes = t_state.binned_passes;
 }
 
 void gs4d_speculation_stats(unsigned long long* issued, unsigned long long* reissued)
@@ -419,9 +437,14 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     if (!ichunk) { gs4d_set_error("image allocator returned NULL"); return GS4D_EALLOC; }
     ImageState im = ImageState::from_chunk(ichunk, (size_t)width * height, gx * gy);
 
+    // How this forward bins its instances: by direct placement (csrc/tile_place.h) when the previous forward of this thread
+    // found the rows of the model in a spatially coherent order (or GS4D_SORT=direct), by the radix passes on the tile bits
+    // otherwise (GS4D_SORT=tile: always).  Same lists either way, bit for bit, in the same half of the binning chunk.
+    const bool direct = gs4d_sort_tile_first() && (gs4d_sort_direct_forced() >= 0 ? gs4d_sort_direct_forced() == 1 : t_state.direct_next);
     int rc = gs4d_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height,
-                                    tan_fovx, tan_fovy, prefiltered, radii, g, debug, s);
+                                    tan_fovx, tan_fovy, prefiltered, radii, g, debug, s,
+                                    direct ? im.tile_cursor : nullptr);
     if (rc) return rc;
     // The one host round trip of the forward (rasterizer_impl.cu:282): num_rendered sizes the binning chunk.  The scan
     // kernel posts ONE 64-bit word (sequence | prefilter flag, num_rendered) into a pinned, coherent host mailbox and the
@@ -443,10 +466,10 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
             (void)hipGetLastError();
         }
     }
-    ts.seq += 2;                                                            // even, bit 0 carries the prefilter flag
-    if (ts.seq == 0) ts.seq = 2;
+    ts.seq += 4;                                // bit 0 carries the prefilter flag, bit 1 "rows spatially coherent"
+    if (ts.seq == 0) ts.seq = 4;
     const uint32_t seq = ts.seq;
-    rc = gs4d_launch_scan(P, g, ts.mailbox, seq, debug, s);
+    rc = gs4d_launch_scan(P, g, ts.mailbox, seq, debug, s, direct ? im.tile_cursor : nullptr, im.tile_base, (int)(gx * gy));
     if (rc) return rc;
 
     const bool with_ckpt = !(debug_arg & GS4D_FORWARD_ONLY);
@@ -474,7 +497,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     if (speculate && bchunk && guess_R <= 0x7fffffffu) {
         char* c = bchunk;
         BinningState bs = BinningState::from_chunk(c, guess_R, sort_passes(width, height), with_ckpt);
-        rc = gs4d_launch_binning(P, (int)guess_R, width, height, radii, g, bs, im, debug, s, g.counters);
+        rc = gs4d_launch_binning(P, (int)guess_R, width, height, radii, g, bs, im, debug, s, g.counters, direct);
         if (!rc)
             rc = gs4d_launch_blend_forward(width, height, g, bs, im, features, background, out_color, out_depth, with_ckpt, debug, s);
         if (rc) {
@@ -485,7 +508,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
         ts.speculated++;
     }
 
-    uint32_t host_counters[2] = {0, 0};
+    uint32_t host_counters[3] = {0, 0, 0};
     bool posted = false;
     const double t_wait0 = gs4d_trace_on() ? gs4d_trace_now_ms() : 0.0;
     if (ts.mailbox) {
@@ -494,9 +517,10 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
         clock_gettime(CLOCK_MONOTONIC, &t0);
         for (unsigned spin = 0;; spin++) {
             const unsigned long long w = __atomic_load_n(ts.mailbox, __ATOMIC_ACQUIRE);   // one word: payload and sequence together
-            if ((uint32_t)(w >> 32 & ~1ull) == seq) {
+            if ((uint32_t)(w >> 32 & ~3ull) == seq) {
                 host_counters[0] = (uint32_t)w;
                 host_counters[1] = (uint32_t)(w >> 32) & 1u;
+                host_counters[2] = (uint32_t)(w >> 32) & 2u;
                 posted = true;
                 break;
             }
@@ -528,6 +552,8 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
         return GS4D_EINVAL;
     }
     const int R = (int)host_counters[0];
+    ts.direct_next = host_counters[2] != 0u;
+    (direct ? ts.binned_direct : ts.binned_passes)++;
     if (num_rendered) *num_rendered = R;
     ts.recent_R[ts.recent_i++ & 7u] = (size_t)R;
     if (spec_issued && (size_t)R <= guess_R) {             // what is in the stream already is the result
@@ -547,7 +573,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     ts.last_R = (size_t)R;
     BinningState b = BinningState::from_chunk(bchunk, (size_t)R, sort_passes(width, height), with_ckpt);
 
-    rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s);
+    rc = gs4d_launch_binning(P, R, width, height, radii, g, b, im, debug, s, nullptr, direct);
     if (rc) return rc;
     return gs4d_launch_blend_forward(width, height, g, b, im, features, background, out_color, out_depth,
                                      !(debug_arg & GS4D_FORWARD_ONLY), debug, s);

@@ -9,6 +9,7 @@
 // All outputs here are integers and must be bit-exact against the oracle.
 #include "gs4d_internal.h"
 #include "gs4d_math.h"
+#include "tile_place.h"
 
 using namespace gs4d;
 
@@ -53,21 +54,35 @@ __device__ __forceinline__ uint32_t resolve_R(uint32_t R_host, const uint32_t* _
 // (391 at P = 100k, 19.5k at P = 5M), so one 1024-lane workgroup looping over chunks is enough.
 // mailbox (may be null): one 64-bit word of pinned, coherent host memory; the kernel posts (seq | prefilter flag) << 32
 // | total with ONE system-scope release store -- payload and sequence number cannot be seen apart -- and the host,
-// polling that word, learns num_rendered without a stream synchronisation (seq is even, never 0).
+// polling that word, learns num_rendered without a stream synchronisation (seq is a multiple of 4, never 0; bit 0 = the
+// prefilter flag, bit 1 = "rows spatially coherent", see below).
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ block_sums,
                                                                uint32_t* __restrict__ block_offsets,
                                                                uint32_t* __restrict__ counters,
-                                                               unsigned long long* __restrict__ mailbox, uint32_t seq)
+                                                               unsigned long long* __restrict__ mailbox, uint32_t seq,
+                                                               const uint32_t* __restrict__ block_area,
+                                                               uint32_t* __restrict__ tile_cursor,
+                                                               uint32_t* __restrict__ tile_base, int ntiles)
 {
     __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_area[16];
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
+    // direct placement: the first 4 096 per-tile counts (four consecutive tiles per lane) are requested now, their latency
+    // passes behind the scan of the block sums
+    uint32_t c[4] = {0u, 0u, 0u, 0u};
+    if (tile_cursor) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) c[q] = tile_cursor[(size_t)min(4 * (int)threadIdx.x + q, ntiles - 1) * GS4D_TILE_CURSOR_STRIDE];
+    }
     __syncthreads();
     int flag = 0;
+    uint32_t area = 0;
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
         const uint32_t raw = i < n ? block_sums[i] : 0u;
+        area += i < n ? block_area[i] : 0u;
         const uint32_t v = raw & 0x7fffffffu;
         flag |= (int)(raw >> 31);
         uint32_t incl = v;
@@ -86,15 +101,67 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
         __syncthreads();
     }
+    // sum of the workgroups' tile rectangles (preprocess launch): an upper bound of the device-scope adds direct placement
+    // needs per phase.  At most a quarter of num_rendered: the rows are in a spatially coherent order, the NEXT forward of
+    // this thread bins by direct placement (api.hip); otherwise by the radix passes.
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) area += __shfl_xor(area, off, 64);
+    if (lane == 0) s_area[wave] = area;
     const int any_flag = __syncthreads_or(flag);
     if (threadIdx.x == 0) {
+        uint32_t area_sum = 0;
+        for (int w = 0; w < 16; w++) area_sum += s_area[w];
+        const uint32_t compact = (s_carry != 0u && (unsigned long long)area_sum * 4ull <= (unsigned long long)s_carry) ? 2u : 0u;
         counters[0] = s_carry;
         counters[1] = any_flag ? 1u : 0u;
+        counters[2] = compact;
         if (mailbox) {
-            const unsigned long long word = ((unsigned long long)(seq | (any_flag ? 1u : 0u)) << 32) | (unsigned long long)s_carry;
+            const unsigned long long word = ((unsigned long long)(seq | compact | (any_flag ? 1u : 0u)) << 32) | (unsigned long long)s_carry;
             __hip_atomic_store(mailbox, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    // Direct placement: tile_cursor holds the instances per tile (counted by the preprocess launch); their exclusive scan
+    // is where each tile's list starts.  tile_base keeps it (the ranges), tile_cursor becomes the list's write cursor.
+    // After the post: the host does not wait for this part.
+    if (tile_cursor == nullptr) return;                  // uniform
+    __syncthreads();
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < ntiles; base += 4096) {
+        const int i0 = base + 4 * (int)threadIdx.x;
+        if (base) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) c[q] = tile_cursor[(size_t)min(i0 + q, ntiles - 1) * GS4D_TILE_CURSOR_STRIDE];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (i0 + q >= ntiles) c[q] = 0u;
+        const uint32_t v = c[0] + c[1] + c[2] + c[3];
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t wave_prefix = 0;
+        for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
+        const uint32_t carry = s_carry;
+        uint32_t run = carry + wave_prefix + incl - v;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (i0 + q < ntiles) {
+                tile_base[i0 + q] = run;
+                tile_cursor[(size_t)(i0 + q) * GS4D_TILE_CURSOR_STRIDE] = run;
+            }
+            run += c[q];
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_base[ntiles] = s_carry;
 }
 
 // ------------------------------------------------------------------ key emission
@@ -184,6 +251,119 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
             const uint64_t key = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | (uint64_t)s_depth[g];
             keys[base + s] = key;
             values[base + s] = (uint32_t)(blockIdx.x * GS4D_PRE_BLOCK + g);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ key emission with direct placement (GS4D_SORT=direct)
+// Same emission as emit_keys_kernel (keys / values in emission order are still written: gs4d_state_view_get shows them),
+// and every instance also goes straight into its tile's list: [tile_base[t], tile_base[t + 1]) of keys_tile /
+// values_tile, laid out by the scan launch from the counts of the preprocess launch.  A list is filled in arbitrary
+// order -- the per-tile sort that follows orders it by depth, then Gaussian index.  Positions are handed out in two
+// levels (tile_place.h): the workgroup counts its Gaussians per tile of its rectangle in LDS, takes one run of positions
+// per tile from the tile's cursor (one device-scope add per tile it touches) and leaves the run's start in the tile's LDS
+// cell; an instance then takes the next position of its cell (ds_add_rtn).
+__global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
+    int P, int gx, int gy, const float2* __restrict__ means2D, const float* __restrict__ depths,
+    const int* __restrict__ radii, const uint32_t* __restrict__ tiles_touched,
+    const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ point_offsets,
+    uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint2* __restrict__ ranges, int ntiles,
+    uint2* __restrict__ seg_owner, int seg_slots, uint32_t cap, const uint32_t* __restrict__ R_dev,
+    uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_base, uint64_t* __restrict__ keys_tile,
+    uint32_t* __restrict__ values_tile)
+{
+    // speculative launch with more instances than it was sized for: the tiles stay empty, nothing is emitted (the cursors
+    // stay where the scan launch put them: the re-issued launch finds them)
+    const bool overflow = R_dev && resolve_R(cap, R_dev) == GS4D_R_OVERFLOW;
+    for (int t = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x; t < ntiles; t += gridDim.x * GS4D_PRE_BLOCK)
+    {
+        const uint32_t b0 = tile_base[t], b1 = tile_base[t + 1];
+        ranges[t] = (overflow || b0 == b1) ? make_uint2(0u, 0u) : make_uint2(b0, b1);   // an empty tile is (0, 0) (rasterizer_impl.cu:311)
+    }
+    for (int t = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x; t < seg_slots; t += gridDim.x * GS4D_PRE_BLOCK)
+        seg_owner[t] = make_uint2(~0u, 0u);
+    if (overflow) return;
+    __shared__ uint32_t s_incl[GS4D_PRE_BLOCK];
+    __shared__ uint32_t s_wave[GS4D_PRE_BLOCK / 64];
+    __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
+    __shared__ uint32_t s_depth[GS4D_PRE_BLOCK];
+    __shared__ uint32_t s_bins[GS4D_AGG_BINS];
+    __shared__ int s_red[GS4D_PRE_BLOCK / 64][4];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int idx = blockIdx.x * GS4D_PRE_BLOCK + tid;
+    uint32_t cnt = 0;
+    int x0 = 0, y0 = 0, x1 = 1, y1 = 1;
+    {
+        const int ld = min(idx, P - 1);
+        const uint32_t c_in = tiles_touched[ld];
+        const float2 m = means2D[ld];
+        const int r_in = radii[ld];
+        const float d_in = depths[ld];
+        if (idx < P) {
+            cnt = c_in;
+            if (cnt) {
+                tile_rect(m.x, m.y, r_in, gx, gy, x0, y0, x1, y1);
+                s_x0[tid] = x0; s_y0[tid] = y0; s_w[tid] = x1 - x0;
+                s_depth[tid] = __float_as_uint(d_in);
+            }
+        }
+    }
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    int bx0, by0, bw, bh;
+    const bool any = block_tile_bbox(cnt != 0u, x0, y0, x1, y1, s_red, bx0, by0, bw, bh);   // barrier inside
+    uint32_t wave_prefix = 0;
+    for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
+    incl += wave_prefix;
+    s_incl[tid] = incl;
+    const uint32_t base = block_offsets[blockIdx.x];
+    if (idx < P) point_offsets[idx] = base + incl;
+    if (!any) return;                                        // uniform: nothing to emit
+    const bool agg = bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;
+    const int pitch = bw + 1;
+    if (agg) {
+        block_tile_counts(cnt != 0u, x0, y0, x1, y1, bx0, by0, bw, bh, s_bins);                // ends with a barrier
+        const int cells = pitch * bh;
+        for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
+            const uint32_t c = s_bins[b];
+            if (c) s_bins[b] = atomicAdd(&tile_cursor[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
+        }
+    }
+    __syncthreads();                                         // s_incl and the cells' run starts
+
+    const uint32_t total = s_incl[GS4D_PRE_BLOCK - 1];
+    for (uint32_t s0 = tid; s0 < total; s0 += 2 * GS4D_PRE_BLOCK) {
+        const uint32_t sv[2] = {s0, min(s0 + (uint32_t)GS4D_PRE_BLOCK, total - 1u)};
+        const bool second = s0 + (uint32_t)GS4D_PRE_BLOCK < total;
+        const int g[2] = {slot_owner(s_incl, sv[0]), slot_owner(s_incl, sv[1])};   // two searches side by side
+        uint64_t key[2];
+        uint32_t val[2], at[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const uint32_t k = sv[q] - (g[q] ? s_incl[g[q] - 1] : 0u);
+            const int w = s_w[g[q]];
+            const int ty = s_y0[g[q]] + (int)(k / (uint32_t)w), tx = s_x0[g[q]] + (int)(k % (uint32_t)w);
+            const uint32_t tile = (uint32_t)(ty * gx + tx);
+            key[q] = ((uint64_t)tile << 32) | (uint64_t)s_depth[g[q]];
+            val[q] = (uint32_t)(blockIdx.x * GS4D_PRE_BLOCK + g[q]);
+            at[q] = 0u;
+            if (q == 0 || second)
+                at[q] = agg ? atomicAdd(&s_bins[(ty - by0) * pitch + (tx - bx0)], 1u)
+                            : atomicAdd(&tile_cursor[(size_t)tile * GS4D_TILE_CURSOR_STRIDE], 1u);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (q == 1 && !second) break;
+            keys[base + sv[q]] = key[q];
+            values[base + sv[q]] = val[q];
+            keys_tile[at[q]] = key[q];
+            values_tile[at[q]] = val[q];
         }
     }
 }
@@ -486,21 +666,25 @@ __device__ __forceinline__ void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// inclusive sum over the 64 lanes (row_shr 1 / 2 / 4 / 8 inside the rows of 16, then row_bcast 15 and 31)
-__device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
-{
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
-    return x;
-}
-
 // begin, n (1 <= n <= 64 R) and tile are wave-uniform.  Loads are unconditional with clamped addresses (a load under a
 // branch makes the compiler wait for every load before it issues the next one).
-template <int R>
+// Position of the list entry (key kp, Gaussian vp) found at `pos` of the depth-sorted list sk / sv (n entries) once every
+// run of EQUAL depths is ordered by Gaussian index: the stable sort of the reference leaves such a run in emission order
+// (ascending index); the direct placement (GS4D_SORT=direct) hands the lists over in arbitrary order, so the order inside
+// a run is restored here.  A Gaussian is at most once in a tile's list: the indices of a run are distinct.
+template <typename K>
+__device__ __forceinline__ uint32_t tie_position(const K* sk, const uint32_t* sv, int n, int pos, uint32_t kp, uint32_t vp)
+{
+    const bool tie = (pos > 0 && (uint32_t)sk[pos - 1] == kp) || (pos + 1 < n && (uint32_t)sk[pos + 1] == kp);
+    if (!tie) return (uint32_t)pos;
+    int first = pos;
+    while (first > 0 && (uint32_t)sk[first - 1] == kp) first--;
+    uint32_t smaller = 0;
+    for (int q = first; q < n && (uint32_t)sk[q] == kp; q++) smaller += sv[q] < vp ? 1u : 0u;
+    return (uint32_t)first + smaller;
+}
+
+template <int R, bool TIES>
 __device__ __forceinline__ void wave_sort_list(WaveSeg& S, uint32_t begin, int n, uint32_t tile, const uint64_t* __restrict__ keys_a,
                                                const uint32_t* __restrict__ vals_a, uint64_t* __restrict__ keys_b,
                                                uint32_t* __restrict__ vals_b)
@@ -577,6 +761,40 @@ __device__ __forceinline__ void wave_sort_list(WaveSeg& S, uint32_t begin, int n
         }
     }
     const uint64_t hi = (uint64_t)tile << 32;
+    if (TIES) {
+        // does ANY entry of the list equal its predecessor?  (entry pos - 1 is the previous lane's slot r: one DPP move,
+        // lane 0 takes lane 63's slot r - 1.)  A handful of lists per frame do; the others leave through the plain stores.
+        bool tie = false;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)k[r], 0x138, 0xf, 0xf, false);   // wave_shr:1
+            if (r > 0) {
+                const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)k[r - 1], 63);
+                if (lane == 0) prev = carry;
+            }
+            const int pos = r * 64 + lane;
+            tie |= pos > 0 && pos < n && prev == k[r];
+        }
+        if (__ballot(tie) != 0ull) {
+            if (!live) {                                      // no pass ran (every depth the same): the list is not in LDS yet
+                wave_sync();
+#pragma unroll
+                for (int r = 0; r < R; r++)
+                    if (r * 64 + lane < n) { S.k[r * 64 + lane] = k[r]; S.v[r * 64 + lane] = v[r]; }
+                wave_sync();
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int pos = r * 64 + lane;
+                if (pos < n) {
+                    const uint32_t at = tie_position(S.k, S.v, n, pos, k[r], v[r]);
+                    keys_b[begin + at] = hi | (uint64_t)k[r];
+                    vals_b[begin + at] = v[r];
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int pos = r * 64 + lane;
@@ -591,7 +809,7 @@ __device__ __forceinline__ void wave_sort_list(WaveSeg& S, uint32_t begin, int n
 // the entries [w 64 R, (w + 1) 64 R) (R = 4 or 8 rounds of 64), ranks them against its own 256 counters (wave-private: no
 // barrier), then the counters of the four waves are combined per digit and scanned (thread = digit), and every entry goes to
 // digit_start[d] + offset of its wave + rank.  Four barriers per pass.
-template <int R>
+template <int R, bool TIES>
 __device__ __forceinline__ void wg_sort_list(SegShared& S, uint32_t begin, int n, uint32_t tile, const uint64_t* __restrict__ keys_a,
                                              const uint32_t* __restrict__ vals_a, uint64_t* __restrict__ keys_b,
                                              uint32_t* __restrict__ vals_b)
@@ -673,6 +891,32 @@ __device__ __forceinline__ void wg_sort_list(SegShared& S, uint32_t begin, int n
         }
     }
     const uint64_t hi = (uint64_t)tile << 32;
+    if (TIES) {                                               // runs of equal depths: by Gaussian index (tie_position)
+        if (!live) {
+#pragma unroll
+            for (int r = 0; r < R; r++)
+                if (base + r * 64 + lane < n) { sk[base + r * 64 + lane] = k[r]; sv[base + r * 64 + lane] = v[r]; }
+            __syncthreads();
+        }
+        int tie = 0;
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int pos = base + r * 64 + lane;
+            tie |= pos > 0 && pos < n && sk[pos - 1] == k[r];
+        }
+        if (__syncthreads_or(tie)) {                          // rare; the other lists leave through the plain stores
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int pos = base + r * 64 + lane;
+                if (pos < n) {
+                    const uint32_t at = tie_position(sk, sv, n, pos, k[r], v[r]);
+                    keys_b[begin + at] = hi | (uint64_t)k[r];
+                    vals_b[begin + at] = v[r];
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int pos = base + r * 64 + lane;
@@ -685,6 +929,7 @@ __device__ __forceinline__ void wg_sort_list(SegShared& S, uint32_t begin, int n
 
 // Grid: blocks [0, ntiles) take the lists LONGER than wave_cap, one workgroup per list (they start first: they are the
 // long poles); blocks [ntiles, ntiles + ceil(ntiles / 4)) take the lists of at most wave_cap entries, one wave per list.
+template <bool TIES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void segment_depth_sort_kernel(const uint2* __restrict__ ranges,
                                                                  uint64_t* __restrict__ keys_a, uint32_t* __restrict__ vals_a,
                                                                  uint64_t* __restrict__ keys_b, uint32_t* __restrict__ vals_b,
@@ -706,9 +951,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #endif
         if (n == 0u || n > wave_cap) return;
         WaveSeg& Sw = U.wv[wave];
-        if (n <= 128u) wave_sort_list<2>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
-        else if (n <= 256u) wave_sort_list<4>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
-        else wave_sort_list<8>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
+        if (n <= 128u) wave_sort_list<2, TIES>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
+        else if (n <= 256u) wave_sort_list<4, TIES>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
+        else wave_sort_list<8, TIES>(Sw, begin, (int)n, t, keys_a, vals_a, keys_b, vals_b);
         return;
     }
     SegShared& S = U.wg;
@@ -723,8 +968,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
     if ((uint32_t)n <= cap) {
         // ---- the list fits (cap <= SEG_CAP = 2048)
-        if (n <= 1024) wg_sort_list<4>(S, range.x, n, tile, keys_a, vals_a, keys_b, vals_b);
-        else wg_sort_list<8>(S, range.x, n, tile, keys_a, vals_a, keys_b, vals_b);
+        if (n <= 1024) wg_sort_list<4, TIES>(S, range.x, n, tile, keys_a, vals_a, keys_b, vals_b);
+        else wg_sort_list<8, TIES>(S, range.x, n, tile, keys_a, vals_a, keys_b, vals_b);
         return;
     }
 
@@ -783,8 +1028,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         __syncthreads();
     }
     for (int i = tid; i < n; i += 256) {
-        keys_b[range.x + i] = keys_a[range.x + i];
-        vals_b[range.x + i] = vals_a[range.x + i];
+        const uint64_t kk = keys_a[range.x + i];
+        const uint32_t vv = vals_a[range.x + i];
+        const uint32_t at = TIES ? tie_position(keys_a + range.x, vals_a + range.x, n, i, (uint32_t)kk, vv) : (uint32_t)i;
+        keys_b[range.x + at] = kk;
+        vals_b[range.x + at] = vv;
     }
 }
 
@@ -838,12 +1086,13 @@ int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_
     return GS4D_OK;
 }
 
-int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t seq, int debug, hipStream_t s)
+int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t seq, int debug, hipStream_t s,
+                     uint32_t* tile_cursor, uint32_t* tile_base, int ntiles)   // tile_cursor != null: direct placement
 {
     GS4D_PROF("scan", s);
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.block_offsets,
-                       g.counters, mailbox, seq);
+                       g.counters, mailbox, seq, g.block_area, tile_cursor, tile_base, ntiles);
     GS4D_LAUNCH_CHECK("scan_block_sums", debug, s);
     return GS4D_OK;
 }
@@ -851,12 +1100,19 @@ int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t 
 // R_dev == nullptr: R is num_rendered.  Otherwise the speculative form: R is the capacity the binning chunk was laid out
 // for, the kernels take the count from *R_dev (GeomState::counters) and do nothing if it exceeds R.
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
-                        int debug, hipStream_t s, const uint32_t* R_dev)
+                        int debug, hipStream_t s, const uint32_t* R_dev, bool direct)
 {
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
+    const int half_in = b.sorted ^ 1;                       // direct placement fills this half, the per-tile sort the other
     {
     GS4D_PROF("emit_keys", s);
+    if (direct)
+        hipLaunchKernelGGL(emit_place_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
+                           radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
+                           im.ranges, gx * gy, b.seg_owner, b.seg_owner ? (int)b.seg_slots : 0, (uint32_t)R, R_dev,
+                           im.tile_cursor, im.tile_base, b.keys_tmp[half_in], b.values_tmp[half_in]);
+    else
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                        radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
                        im.ranges, gx * gy, b.seg_owner, b.seg_owner ? (int)b.seg_slots : 0,    // no slots on a forward-only call
@@ -869,7 +1125,19 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
     const uint32_t tbits = gs4d_higher_msb((uint32_t)(gx * gy));
     int where = 0;
     int rc;
-    if (gs4d_sort_tile_first()) {
+    if (direct) {
+        // The tile lists are in place, in arbitrary order inside a list: one launch sorts each by depth, then Gaussian
+        // index (the order the reference's stable sort leaves), into the half the radix passes would have ended in (the
+        // backward and the state view find the lists without knowing how they were binned).  A speculative launch that
+        // overflowed left every range empty.
+        GS4D_PROF("radix_sort", s);
+        const uint32_t nt = (uint32_t)(gx * gy), cap = gs4d_sort_segment_cap();
+        const uint32_t wave_cap = cap < gs4d_sort_wave_cap() ? cap : gs4d_sort_wave_cap();
+        hipLaunchKernelGGL(segment_depth_sort_kernel<true>, dim3(nt + (nt + 3) / 4), dim3(256), 0, s, im.ranges, b.keys_tmp[half_in],
+                           b.values_tmp[half_in], b.keys_tmp[b.sorted], b.values_tmp[b.sorted], cap, wave_cap, nt);
+        GS4D_LAUNCH_CHECK("segment_depth_sort", debug, s);
+        where = b.sorted;
+    } else if (gs4d_sort_tile_first()) {
         GS4D_PROF("radix_sort", s);
         const int tpasses = (int)((tbits + 7) / 8);
         rc = gs4d_radix_sort_pairs((uint32_t)R, tpasses, 32, b.keys_unsorted, b.values_unsorted, b.keys_tmp, b.values_tmp,
@@ -879,7 +1147,7 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
                            b.keys_tmp[where], im.ranges, R_dev);
         const uint32_t nt = (uint32_t)(gx * gy), cap = gs4d_sort_segment_cap();
         const uint32_t wave_cap = cap < gs4d_sort_wave_cap() ? cap : gs4d_sort_wave_cap();
-        hipLaunchKernelGGL(segment_depth_sort_kernel, dim3(nt + (nt + 3) / 4), dim3(256), 0, s, im.ranges, b.keys_tmp[where],
+        hipLaunchKernelGGL(segment_depth_sort_kernel<false>, dim3(nt + (nt + 3) / 4), dim3(256), 0, s, im.ranges, b.keys_tmp[where],
                            b.values_tmp[where], b.keys_tmp[where ^ 1], b.values_tmp[where ^ 1], cap, wave_cap, nt);
         GS4D_LAUNCH_CHECK("segment_depth_sort", debug, s);
         where ^= 1;
@@ -891,8 +1159,8 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
         if (rc) return rc;
     }
     if (where != b.sorted) { gs4d_set_error("binning: sorted lists ended in buffer %d, layout expects %d", where, b.sorted); return GS4D_EINVAL; }
-    // ranges: already written by tile_bounds_kernel in tile-first order
-    if (!gs4d_sort_tile_first()) {
+    // ranges: already written by tile_bounds_kernel in tile-first order, by emit_place_kernel in direct placement
+    if (!direct && !gs4d_sort_tile_first()) {
         GS4D_PROF("tile_ranges", s);
         hipLaunchKernelGGL(tile_ranges_kernel, dim3(((uint32_t)R + 255) / 256), dim3(256), 0, s, (uint32_t)R, b.keys_sorted(),
                            im.ranges, R_dev);

@@ -90,16 +90,24 @@ struct GeomState {
     uint32_t* point_offsets;  // [P] inclusive scan of tiles_touched
     uint32_t* block_sums;     // [ceil(P/256)]
     uint32_t* block_offsets;  // [ceil(P/256)] exclusive scan of block_sums
-    uint32_t* counters;       // [64] counters[0] = num_rendered, counters[1] = prefilter violation flag
+    uint32_t* counters;       // [64] counters[0] = num_rendered, counters[1] = prefilter violation flag, counters[2] = 2 if
+                              // the rows are spatially coherent (scan_block_sums_kernel), else 0
+    uint32_t* block_area;     // [ceil(P/256)] tiles in the rectangle around the workgroup's Gaussians (preprocess launch)
     static GeomState from_chunk(char*& chunk, size_t P);
     static size_t required(size_t P);
 };
 
+#define GS4D_TILE_CURSOR_STRIDE 32
 struct ImageState {
     float* final_T;           // [H*W]
     uint32_t* n_contrib;      // [H*W]
     uint2* ranges;            // [tiles]
     uint32_t* tile_max_contrib; // [tiles] max n_contrib over the tile's pixels (written by the forward blend)
+    // GS4D_SORT=direct (binning.hip): instances per tile, counted by the preprocess launch (cleared in front of it), turned
+    // into each list's write cursor by the scan launch; tile_base = the lists' first positions, [tiles] = num_rendered
+    uint32_t* tile_cursor;    // [tiles][GS4D_TILE_CURSOR_STRIDE]: one counter per 128-byte line (the memory-side atomics
+                              // serialise per line: 16 tiles to a line made the counting 52 us at C2 instead of ~5)
+    uint32_t* tile_base;      // [tiles + 1]
     static ImageState from_chunk(char*& chunk, size_t npix, size_t ntiles);
     static size_t required(size_t npix, size_t ntiles);
 };
@@ -141,6 +149,9 @@ static inline uint32_t gs4d_higher_msb(uint32_t n)
 // sort strategy of the binning stage (process-wide, read once from the environment: GS4D_SORT=lsd selects the
 // six-pass LSD sort; default is tile-first, see binning.hip) and the longest per-tile list sorted inside LDS
 bool gs4d_sort_tile_first();
+// GS4D_SORT=direct / tile: counted placement into the tile lists (csrc/tile_place.h) always / never; unset: per forward,
+// decided by what the previous forward of the thread measured.  -1 = not forced, 0 = never, 1 = always.
+int gs4d_sort_direct_forced();
 uint32_t gs4d_sort_segment_cap();
 uint32_t gs4d_sort_wave_cap();
 int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
@@ -152,7 +163,8 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, const float* opacities, const float* shs,
                            const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
-                           float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s);
+                           float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s,
+                           uint32_t* tile_count = nullptr);
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 // csrc/api.hip: the rasterizer entry points with the speculative binning launch / an explicit binning layout (csrc/render.hip)
 int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
@@ -174,7 +186,7 @@ int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ct
                                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
                                    void* stream, int layout_rendered);
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
-                        int debug, hipStream_t s, const uint32_t* R_dev = nullptr);
+                        int debug, hipStream_t s, const uint32_t* R_dev = nullptr, bool direct = false);
 // the deferred-Gaussian counter of the backward scratch (layout: gs4d_backward_scratch_bytes)
 static inline uint32_t* gs4d_backward_big_count(const float* inst_grad, int R)
 {

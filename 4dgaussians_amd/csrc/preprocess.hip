@@ -11,6 +11,7 @@
 // bound: 236 B read + 75 B written per Gaussian.
 #include "gs4d_internal.h"
 #include "gs4d_math.h"
+#include "tile_place.h"
 
 using namespace gs4d;
 
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     int W, int H, float tan_fovx, float tan_fovy, float focal_x, float focal_y, int gx, int gy, int prefiltered,
     int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds,
     float* __restrict__ rgb, float4* __restrict__ conic_opacity, uint8_t* __restrict__ clamped,
-    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums)
+    uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_area,
+    uint32_t* __restrict__ tile_count)
 {
     __shared__ float s_view[16], s_proj[16], s_cam[3];
     __shared__ uint32_t s_wave_sum[GS4D_PRE_BLOCK / 64];
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     const int idx = blockIdx.x * GS4D_PRE_BLOCK + threadIdx.x;
     uint32_t my_tiles = 0;
     int my_radius_i = 0;
+    int my_x0 = 0, my_y0 = 0, my_x1 = 1, my_y1 = 1;
     int bad = 0;
     // Every input of the Gaussian is requested up front, before the first test that could skip it: under the near-plane /
     // empty-rectangle branches the scales, the rotation, the opacity and the 48 SH floats were three memory latencies in
@@ -148,6 +151,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
                     conic_opacity[idx] = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, op_in);
                     my_radius_i = (int)my_radius;
                     my_tiles = ntiles;
+                    my_x0 = x0; my_y0 = y0; my_x1 = x1; my_y1 = y1;
                 }
             }
         } else if (prefiltered) {
@@ -170,6 +174,32 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
         for (int w = 0; w < GS4D_PRE_BLOCK / 64; w++) t += s_wave_sum[w];
         block_sums[blockIdx.x] = (t & 0x7fffffffu) | (any_bad ? 0x80000000u : 0u);
     }
+
+    // The rectangle of tiles around the workgroup's Gaussians: small when the rows are in a spatially coherent order.  The
+    // scan launch adds the areas up and tells the host whether direct placement pays (binning.hip, api.hip).
+    __shared__ int s_red[GS4D_PRE_BLOCK / 64][4];
+    int bx0, by0, bw, bh;
+    const bool any = block_tile_bbox(my_tiles != 0u, my_x0, my_y0, my_x1, my_y1, s_red, bx0, by0, bw, bh);   // barrier inside
+    if (threadIdx.x == 0) block_area[blockIdx.x] = any ? (uint32_t)(bw * bh) : 0u;
+
+    // Direct placement (tile_place.h): the (Gaussian, tile) instances are counted per tile here, so that the scan launch can
+    // lay the tile lists out before the keys exist: counts of the workgroup's own Gaussians over its rectangle of tiles in
+    // LDS (four adds per Gaussian), then one device-scope add per tile it touches.
+    if (tile_count == nullptr || !any) return;              // uniform
+    __shared__ uint32_t s_bins[GS4D_AGG_BINS];
+    const int tid = threadIdx.x;
+    if (bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE) {
+        block_tile_counts(my_tiles != 0u, my_x0, my_y0, my_x1, my_y1, bx0, by0, bw, bh, s_bins);
+        const int pitch = bw + 1, cells = pitch * bh;
+        for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
+            const uint32_t c = s_bins[b];
+            if (c) atomicAdd(&tile_count[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
+        }
+    } else if (my_tiles != 0u) {
+        // rows in no spatial order, or a splat over most of the image: one add per instance, each lane its own rectangle
+        for (int ty = my_y0; ty < my_y1; ty++)
+            for (int tx = my_x0; tx < my_x1; tx++) atomicAdd(&tile_count[(size_t)(ty * gx + tx) * GS4D_TILE_CURSOR_STRIDE], 1u);
+    }
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,
@@ -189,18 +219,20 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* rotations, const float* opacities, const float* shs,
                            const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
-                           float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s)
+                           float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s,
+                           uint32_t* tile_count)
 {
     GS4D_PROF("preprocess", s);
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
+    if (tile_count) GS4D_HIP_CHECK(hipMemsetAsync(tile_count, 0, (size_t)gx * gy * GS4D_TILE_CURSOR_STRIDE * sizeof(uint32_t), s));
     hipLaunchKernelGGL(preprocess_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                        projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, prefiltered, radii,
                        g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.clamped, g.tiles_touched,
-                       g.block_sums);
+                       g.block_sums, g.block_area, tile_count);
     GS4D_LAUNCH_CHECK("preprocess", debug, s);
     return GS4D_OK;
 }
