@@ -72,7 +72,12 @@ def speculation_stats():
 def binning_stats():
     """(direct, passes): forwards of this thread binned by direct placement / by the radix passes on the tile bits
     (include/gs4d.h: gs4d_binning_stats)."""
-    v = [C.c_ulonglong(0) for _ in range(2)]
+    return binning_stats_full()[:2]
+
+
+def binning_stats_full():
+    """(direct, passes, last_rect_tiles, last_rendered) of gs4d_binning_stats."""
+    v = [C.c_ulonglong(0) for _ in range(4)]
     lib().gs4d_binning_stats(*(C.byref(x) for x in v))
     return tuple(x.value for x in v)
 

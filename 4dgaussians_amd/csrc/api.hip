@@ -30,7 +30,7 @@ struct ThreadState {
     size_t recent_R[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last eight counts: the speculative launch sizes for their maximum
     unsigned recent_i = 0;
     bool direct_next = false;                   // the last forward found the rows spatially coherent: bin by direct placement
-    unsigned long long binned_direct = 0, binned_passes = 0;
+    unsigned long long binned_direct = 0, binned_passes = 0, last_rect_tiles = 0, last_rendered = 0;
     unsigned long long speculated = 0, respun = 0;  // forwards whose binning + blend were issued before the count was read / of those, re-issued
     unsigned long long fast = 0, slow = 0;      // how often the count arrived through the mailbox / the copy + sync path
     unsigned long long regrow = 0;              // forwards whose speculative binning chunk was too small (second allocation)
@@ -320,10 +320,13 @@ void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsi
     if (regrow) *regrow = t_state.regrow;
 }
 
-void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes)
+void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes, unsigned long long* last_rect_tiles,
+                        unsigned long long* last_rendered)
 {
     if (direct) *direct = t_state.binned_direct;
     if (passes) *passes = t_state.binned_passes;
+    if (last_rect_tiles) *last_rect_tiles = t_state.last_rect_tiles;
+    if (last_rendered) *last_rendered = t_state.last_rendered;
 }
 
 void gs4d_speculation_stats(unsigned long long* issued, unsigned long long* reissued)
@@ -508,7 +511,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
         ts.speculated++;
     }
 
-    uint32_t host_counters[3] = {0, 0, 0};
+    uint32_t host_counters[4] = {0, 0, 0, 0};
     bool posted = false;
     const double t_wait0 = gs4d_trace_on() ? gs4d_trace_now_ms() : 0.0;
     if (ts.mailbox) {
@@ -521,6 +524,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
                 host_counters[0] = (uint32_t)w;
                 host_counters[1] = (uint32_t)(w >> 32) & 1u;
                 host_counters[2] = (uint32_t)(w >> 32) & 2u;
+                host_counters[3] = (uint32_t)__atomic_load_n(ts.mailbox + 1, __ATOMIC_RELAXED);   // written before the post
                 posted = true;
                 break;
             }
@@ -553,6 +557,8 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     }
     const int R = (int)host_counters[0];
     ts.direct_next = host_counters[2] != 0u;
+    ts.last_rect_tiles = host_counters[3];
+    ts.last_rendered = host_counters[0];
     (direct ? ts.binned_direct : ts.binned_passes)++;
     if (num_rendered) *num_rendered = R;
     ts.recent_R[ts.recent_i++ & 7u] = (size_t)R;

@@ -102,7 +102,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         __syncthreads();
     }
     // sum of the workgroups' tile rectangles (preprocess launch): an upper bound of the device-scope adds direct placement
-    // needs per phase.  At most a quarter of num_rendered: the rows are in a spatially coherent order, the NEXT forward of
+    // needs per phase (a loose one: C2's eight views give 0.45 of num_rendered where the adds that actually happen are
+    // ~0.1 of it, rows in no order give 1.0).  At most half of num_rendered: the rows count as spatially coherent, the NEXT forward of
     // this thread bins by direct placement (api.hip); otherwise by the radix passes.
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) area += __shfl_xor(area, off, 64);
@@ -111,11 +112,13 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
     if (threadIdx.x == 0) {
         uint32_t area_sum = 0;
         for (int w = 0; w < 16; w++) area_sum += s_area[w];
-        const uint32_t compact = (s_carry != 0u && (unsigned long long)area_sum * 4ull <= (unsigned long long)s_carry) ? 2u : 0u;
+        const uint32_t compact = (s_carry != 0u && (unsigned long long)area_sum * 2ull <= (unsigned long long)s_carry) ? 2u : 0u;
         counters[0] = s_carry;
         counters[1] = any_flag ? 1u : 0u;
         counters[2] = compact;
+        counters[3] = area_sum;
         if (mailbox) {
+            mailbox[1] = (unsigned long long)area_sum;       // diagnostics (gs4d_binning_stats); ordered before the post below
             const unsigned long long word = ((unsigned long long)(seq | compact | (any_flag ? 1u : 0u)) << 32) | (unsigned long long)s_carry;
             __hip_atomic_store(mailbox, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
@@ -288,7 +291,8 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
     __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
     __shared__ uint32_t s_depth[GS4D_PRE_BLOCK];
     __shared__ uint32_t s_bins[GS4D_AGG_BINS];
-    __shared__ int s_red[GS4D_PRE_BLOCK / 64][4];
+    __shared__ int s_red[GS4D_PRE_BLOCK / 64][6];
+    __shared__ uint8_t s_big[GS4D_PRE_BLOCK];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int idx = blockIdx.x * GS4D_PRE_BLOCK + tid;
@@ -316,26 +320,30 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
         if (lane >= off) incl += t;
     }
     if (lane == 63) s_wave[wave] = incl;
+    // the same split as in the preprocess launch: big splats apart, the others inside the workgroup's rectangle
+    const bool big = cnt != 0u && tile_rect_is_big(x0, y0, x1, y1);
+    const bool small = cnt != 0u && !big;
     int bx0, by0, bw, bh;
-    const bool any = block_tile_bbox(cnt != 0u, x0, y0, x1, y1, s_red, bx0, by0, bw, bh);   // barrier inside
+    uint32_t unused_a = 0, unused_b = 0;
+    const bool any_small = block_tile_bbox(small, x0, y0, x1, y1, s_red, bx0, by0, bw, bh, unused_a, unused_b);   // barrier inside
     uint32_t wave_prefix = 0;
     for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
     incl += wave_prefix;
     s_incl[tid] = incl;
     const uint32_t base = block_offsets[blockIdx.x];
     if (idx < P) point_offsets[idx] = base + incl;
-    if (!any) return;                                        // uniform: nothing to emit
-    const bool agg = bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;
+    const bool agg = any_small && bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;   // uniform
+    s_big[tid] = (uint8_t)(agg ? big : true);                // 1: the Gaussian's instances take their position from the tile's cursor itself
     const int pitch = bw + 1;
     if (agg) {
-        block_tile_counts(cnt != 0u, x0, y0, x1, y1, bx0, by0, bw, bh, s_bins);                // ends with a barrier
+        block_tile_counts(small, x0, y0, x1, y1, bx0, by0, bw, bh, s_bins);                    // ends with a barrier
         const int cells = pitch * bh;
         for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
             const uint32_t c = s_bins[b];
             if (c) s_bins[b] = atomicAdd(&tile_cursor[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
         }
     }
-    __syncthreads();                                         // s_incl and the cells' run starts
+    __syncthreads();                                         // s_incl, s_big and the cells' run starts
 
     const uint32_t total = s_incl[GS4D_PRE_BLOCK - 1];
     for (uint32_t s0 = tid; s0 < total; s0 += 2 * GS4D_PRE_BLOCK) {
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
             val[q] = (uint32_t)(blockIdx.x * GS4D_PRE_BLOCK + g[q]);
             at[q] = 0u;
             if (q == 0 || second)
-                at[q] = agg ? atomicAdd(&s_bins[(ty - by0) * pitch + (tx - bx0)], 1u)
-                            : atomicAdd(&tile_cursor[(size_t)tile * GS4D_TILE_CURSOR_STRIDE], 1u);
+                at[q] = s_big[g[q]] ? atomicAdd(&tile_cursor[(size_t)tile * GS4D_TILE_CURSOR_STRIDE], 1u)
+                                    : atomicAdd(&s_bins[(ty - by0) * pitch + (tx - bx0)], 1u);
         }
 #pragma unroll
         for (int q = 0; q < 2; q++) {

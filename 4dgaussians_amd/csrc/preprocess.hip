@@ -175,30 +175,42 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
         block_sums[blockIdx.x] = (t & 0x7fffffffu) | (any_bad ? 0x80000000u : 0u);
     }
 
-    // The rectangle of tiles around the workgroup's Gaussians: small when the rows are in a spatially coherent order.  The
-    // scan launch adds the areas up and tells the host whether direct placement pays (binning.hip, api.hip).
-    __shared__ int s_red[GS4D_PRE_BLOCK / 64][4];
+    // The rectangle of tiles around the workgroup's Gaussians (the big splats apart): small when the rows are in a spatially
+    // coherent order.  block_area = the device-scope adds direct placement would need for this workgroup per phase, at
+    // most: one per tile of the rectangle or per instance of a Gaussian in it, whichever is fewer, + one per instance of a
+    // big splat.  The scan launch adds them up and tells the host whether direct placement pays (binning.hip, api.hip).
+    __shared__ int s_red[GS4D_PRE_BLOCK / 64][6];
+    const bool big = my_tiles != 0u && tile_rect_is_big(my_x0, my_y0, my_x1, my_y1);
+    const bool small = my_tiles != 0u && !big;
     int bx0, by0, bw, bh;
-    const bool any = block_tile_bbox(my_tiles != 0u, my_x0, my_y0, my_x1, my_y1, s_red, bx0, by0, bw, bh);   // barrier inside
-    if (threadIdx.x == 0) block_area[blockIdx.x] = any ? (uint32_t)(bw * bh) : 0u;
+    uint32_t small_tiles = small ? my_tiles : 0u, big_tiles = big ? my_tiles : 0u;
+    const bool any_small = block_tile_bbox(small, my_x0, my_y0, my_x1, my_y1, s_red, bx0, by0, bw, bh, small_tiles, big_tiles);   // barrier inside
+    if (threadIdx.x == 0) block_area[blockIdx.x] = (any_small ? min((uint32_t)(bw * bh), small_tiles) : 0u) + big_tiles;
 
     // Direct placement (tile_place.h): the (Gaussian, tile) instances are counted per tile here, so that the scan launch can
     // lay the tile lists out before the keys exist: counts of the workgroup's own Gaussians over its rectangle of tiles in
     // LDS (four adds per Gaussian), then one device-scope add per tile it touches.
-    if (tile_count == nullptr || !any) return;              // uniform
+    if (tile_count == nullptr) return;                      // uniform
     __shared__ uint32_t s_bins[GS4D_AGG_BINS];
-    const int tid = threadIdx.x;
-    if (bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE) {
-        block_tile_counts(my_tiles != 0u, my_x0, my_y0, my_x1, my_y1, bx0, by0, bw, bh, s_bins);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const bool agg = any_small && bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;   // uniform
+    if (agg) {
+        block_tile_counts(small, my_x0, my_y0, my_x1, my_y1, bx0, by0, bw, bh, s_bins);
         const int pitch = bw + 1, cells = pitch * bh;
         for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
             const uint32_t c = s_bins[b];
             if (c) atomicAdd(&tile_count[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
         }
-    } else if (my_tiles != 0u) {
-        // rows in no spatial order, or a splat over most of the image: one add per instance, each lane its own rectangle
-        for (int ty = my_y0; ty < my_y1; ty++)
-            for (int tx = my_x0; tx < my_x1; tx++) atomicAdd(&tile_count[(size_t)(ty * gx + tx) * GS4D_TILE_CURSOR_STRIDE], 1u);
+    }
+    // one add per instance: the big splats (and everything, if the rows are in no spatial order), a wave per Gaussian
+    unsigned long long todo = __ballot(agg ? big : my_tiles != 0u);
+    while (todo) {
+        const int src = __ffsll(todo) - 1;
+        todo &= todo - 1ull;
+        const int x0 = __shfl(my_x0, src, 64), y0 = __shfl(my_y0, src, 64), w = __shfl(my_x1, src, 64) - x0;
+        const int n = (int)__shfl((int)my_tiles, src, 64);
+        for (int k = lane; k < n; k += 64)
+            atomicAdd(&tile_count[(size_t)((y0 + k / w) * gx + x0 + k % w) * GS4D_TILE_CURSOR_STRIDE], 1u);
     }
 }
 

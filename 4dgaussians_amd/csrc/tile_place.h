@@ -11,14 +11,17 @@
 // leaves one device-scope add per DISTINCT tile of the workgroup (57 k per phase instead of 768 k).  The LDS counts come
 // from a 2-D difference array: four LDS adds per Gaussian (+1 / -1 at the corners of its rectangle) and a prefix sum
 // along x, then y -- one LDS add per INSTANCE ran at the ~0.3 lanes per clock of conflicting ds_add (14 us in the
-// preprocess launch).  A workgroup whose rectangle is wider or taller than 63 tiles (rows in no spatial order, one
-// splat over the whole image) falls back to one device-scope add per instance.
+// preprocess launch).  A splat wider or taller than GS4D_BIG_SIDE tiles stays out of the rectangle (one of them would
+// blow it up for its whole workgroup) and takes one device-scope add per instance: its instances are distinct tiles
+// anyway.  A workgroup whose rectangle is still wider or taller than 63 tiles (rows in no spatial order) falls back to one
+// device-scope add per instance for all its Gaussians.
 #pragma once
 #include "gs4d_internal.h"
 #include <limits.h>
 
 #define GS4D_AGG_SIDE 64           // the rectangle + one guard row / column fits 64 x 64 cells (16 KB)
 #define GS4D_AGG_BINS (GS4D_AGG_SIDE * GS4D_AGG_SIDE)
+#define GS4D_BIG_SIDE 24           // a splat over more tiles than this in x or y is placed instance by instance (12: +2.6 us at C2, 48: same)
 
 namespace gs4d {
 
@@ -34,26 +37,40 @@ __device__ __forceinline__ uint32_t wave_inclusive_sum(uint32_t x)
     return x;
 }
 
+__device__ __forceinline__ bool tile_rect_is_big(int x0, int y0, int x1, int y1)
+{
+    return x1 - x0 > GS4D_BIG_SIDE || y1 - y0 > GS4D_BIG_SIDE;
+}
+
 // Rectangle [bx0, bx0 + bw) x [by0, by0 + bh) of tiles around the rectangles of the workgroup's lanes (has = the lane's
-// Gaussian touches tiles [x0, x1) x [y0, y1)); false if no lane has one.  One workgroup barrier.
-__device__ __forceinline__ bool block_tile_bbox(bool has, int x0, int y0, int x1, int y1, int (*s_red)[4], int& bx0, int& by0,
-                                                int& bw, int& bh)
+// Gaussian touches tiles [x0, x1) x [y0, y1) and is not big); false if no lane has one.  sum_a / sum_b: two per-lane
+// numbers summed over the workgroup on the way (in: the lane's, out: the workgroup's).  One workgroup barrier.
+__device__ __forceinline__ bool block_tile_bbox(bool has, int x0, int y0, int x1, int y1, int (*s_red)[6], int& bx0, int& by0,
+                                                int& bw, int& bh, uint32_t& sum_a, uint32_t& sum_b)
 {
     int a = has ? x0 : INT_MAX, b = has ? y0 : INT_MAX, c = has ? x1 : 0, d = has ? y1 : 0;
+    uint32_t e = sum_a, f = sum_b;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         a = min(a, __shfl_xor(a, off, 64));
         b = min(b, __shfl_xor(b, off, 64));
         c = max(c, __shfl_xor(c, off, 64));
         d = max(d, __shfl_xor(d, off, 64));
+        e += __shfl_xor(e, off, 64);
+        f += __shfl_xor(f, off, 64);
     }
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { s_red[wave][0] = a; s_red[wave][1] = b; s_red[wave][2] = c; s_red[wave][3] = d; }
+    if ((threadIdx.x & 63) == 0) {
+        s_red[wave][0] = a; s_red[wave][1] = b; s_red[wave][2] = c; s_red[wave][3] = d; s_red[wave][4] = (int)e; s_red[wave][5] = (int)f;
+    }
     __syncthreads();
+    a = INT_MAX; b = INT_MAX; c = 0; d = 0; e = 0; f = 0;
 #pragma unroll
     for (int w = 0; w < GS4D_PRE_BLOCK / 64; w++) {
         a = min(a, s_red[w][0]); b = min(b, s_red[w][1]); c = max(c, s_red[w][2]); d = max(d, s_red[w][3]);
+        e += (uint32_t)s_red[w][4]; f += (uint32_t)s_red[w][5];
     }
+    sum_a = e; sum_b = f;
     if (c == 0) { bx0 = by0 = 0; bw = bh = 1; return false; }
     bx0 = a; by0 = b; bw = c - a; bh = d - b;
     return true;

@@ -267,6 +267,7 @@ def main():
     L.gs4d_profile_enable(0 if args.no_stage_events else 1)
     stats0 = cabi.forward_stats()
     spec0 = cabi.speculation_stats()
+    bin0 = cabi.binning_stats_full()
     step_no[0] = 0                          # the timed region renders views 0, 1, ..., steps - 1 (mod V)
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -276,6 +277,7 @@ def main():
     dt = time.perf_counter() - t0
     stats1 = cabi.forward_stats()
     spec1 = cabi.speculation_stats()
+    bin1 = cabi.binning_stats_full()
     nviews_timed = args.steps * (VPG if args.mode == "train" else 1)
     view_weight = [sum(1 for i in range(nviews_timed) if i % V == j) / nviews_timed for j in range(V)]
     _dbg(f"host had issued the last step after {t_issued / args.steps * 1e3:.3f} ms per step")
@@ -496,6 +498,10 @@ def main():
                        # num_rendered had been read / of those, issued again; plane-gradient point orders ranked / reused
                        "timed_region": {"copy_sync_fallback": stats1[1] - stats0[1], "binning_second_allocations": stats1[2] - stats0[2],
                                         "speculative_forwards": {"issued": spec1[0] - spec0[0], "reissued": spec1[1] - spec0[1]},
+                                        # how the forwards were binned (include/gs4d.h: gs4d_binning_stats) and the last
+                                        # forward's two numbers that the choice rests on
+                                        "binning": {"direct_placement": bin1[0] - bin0[0], "radix_passes": bin1[1] - bin0[1],
+                                                    "last_rect_tiles": bin1[2], "last_rendered": bin1[3]},
                                         "hex_order": hex_order_counts()},
                        # memory of the per-view binning state (keys, values, sort buffers, histograms + the blend's segment
                        # checkpoints that only a training forward reserves), per rendered instance

@@ -45,7 +45,7 @@ def test_sort_strategies_agree_bit_for_bit():
 def test_binning_follows_the_row_order_of_the_model():
     """Unforced (GS4D_SORT unset), the forward bins by direct placement when the PREVIOUS forward of the thread found the
     rows spatially coherent (scan_block_sums_kernel: the tile rectangles around every 256 consecutive Gaussians sum to at
-    most a quarter of num_rendered), by the radix passes otherwise: i.i.d. rows stay on the passes, the same Gaussians in
+    most half of num_rendered), by the radix passes otherwise: i.i.d. rows stay on the passes, the same Gaussians in
     Morton order switch after one forward, and both give the same lists and image bit for bit."""
     if os.environ.get("GS4D_SORT"):
         pytest.skip("binning strategy forced by GS4D_SORT")
@@ -56,7 +56,7 @@ def test_binning_follows_the_row_order_of_the_model():
     syn = importlib.import_module("4dgaussians_amd.synthetic")
     wl = importlib.import_module("4dgaussians_amd.workload")
     cabi = importlib.import_module("4dgaussians_amd._cabi")
-    P, W, H = 30000, 640, 480
+    P, W, H = 30000, 1280, 960
     cam = syn.look_at_camera(W, H)
     raw = syn.make_gaussians(P, 11, 0.02)
     a = syn.activate(raw)
