@@ -76,7 +76,7 @@ def binning_stats():
 
 
 def binning_stats_full():
-    """(direct, passes, last_rect_tiles, last_rendered) of gs4d_binning_stats."""
+    """(direct, passes, last_adds, last_rendered) of gs4d_binning_stats."""
     v = [C.c_ulonglong(0) for _ in range(4)]
     lib().gs4d_binning_stats(*(C.byref(x) for x in v))
     return tuple(x.value for x in v)

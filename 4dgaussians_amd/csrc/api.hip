@@ -29,8 +29,8 @@ struct ThreadState {
     size_t last_R = 0;
     size_t recent_R[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the last eight counts: the speculative launch sizes for their maximum
     unsigned recent_i = 0;
-    bool direct_next = false;                   // the last forward found the rows spatially coherent: bin by direct placement
-    unsigned long long binned_direct = 0, binned_passes = 0, last_rect_tiles = 0, last_rendered = 0;
+    bool direct_next = false;                   // the last forward's counts say direct placement is the cheaper binning (binning.hip)
+    unsigned long long binned_direct = 0, binned_passes = 0, last_adds = 0, last_rendered = 0;
     unsigned long long speculated = 0, respun = 0;  // forwards whose binning + blend were issued before the count was read / of those, re-issued
     unsigned long long fast = 0, slow = 0;      // how often the count arrived through the mailbox / the copy + sync path
     unsigned long long regrow = 0;              // forwards whose speculative binning chunk was too small (second allocation)
@@ -320,12 +320,12 @@ void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsi
     if (regrow) *regrow = t_state.regrow;
 }
 
-void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes, unsigned long long* last_rect_tiles,
+void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes, unsigned long long* last_adds,
                         unsigned long long* last_rendered)
 {
     if (direct) *direct = t_state.binned_direct;
     if (passes) *passes = t_state.binned_passes;
-    if (last_rect_tiles) *last_rect_tiles = t_state.last_rect_tiles;
+    if (last_adds) *last_adds = t_state.last_adds;
     if (last_rendered) *last_rendered = t_state.last_rendered;
 }
 
@@ -440,9 +440,9 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     if (!ichunk) { gs4d_set_error("image allocator returned NULL"); return GS4D_EALLOC; }
     ImageState im = ImageState::from_chunk(ichunk, (size_t)width * height, gx * gy);
 
-    // How this forward bins its instances: by direct placement (csrc/tile_place.h) when the previous forward of this thread
-    // found the rows of the model in a spatially coherent order (or GS4D_SORT=direct), by the radix passes on the tile bits
-    // otherwise (GS4D_SORT=tile: always).  Same lists either way, bit for bit, in the same half of the binning chunk.
+    // How this forward bins its instances: by direct placement (csrc/tile_place.h) when the counts of the previous forward
+    // of this thread say it is the cheaper way (few instances, rows in a spatially coherent order: scan_block_sums_kernel;
+    // or GS4D_SORT=direct), by the radix passes on the tile bits otherwise (GS4D_SORT=tile: always).  Same lists either way, bit for bit, in the same half of the binning chunk.
     const bool direct = gs4d_sort_tile_first() && (gs4d_sort_direct_forced() >= 0 ? gs4d_sort_direct_forced() == 1 : t_state.direct_next);
     int rc = gs4d_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height,
@@ -469,7 +469,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
             (void)hipGetLastError();
         }
     }
-    ts.seq += 4;                                // bit 0 carries the prefilter flag, bit 1 "rows spatially coherent"
+    ts.seq += 4;                                // bit 0 carries the prefilter flag, bit 1 "direct placement next"
     if (ts.seq == 0) ts.seq = 4;
     const uint32_t seq = ts.seq;
     rc = gs4d_launch_scan(P, g, ts.mailbox, seq, debug, s, direct ? im.tile_cursor : nullptr, im.tile_base, (int)(gx * gy));
@@ -557,7 +557,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     }
     const int R = (int)host_counters[0];
     ts.direct_next = host_counters[2] != 0u;
-    ts.last_rect_tiles = host_counters[3];
+    ts.last_adds = host_counters[3];
     ts.last_rendered = host_counters[0];
     (direct ? ts.binned_direct : ts.binned_passes)++;
     if (num_rendered) *num_rendered = R;

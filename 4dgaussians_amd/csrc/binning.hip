@@ -55,7 +55,7 @@ __device__ __forceinline__ uint32_t resolve_R(uint32_t R_host, const uint32_t* _
 // mailbox (may be null): one 64-bit word of pinned, coherent host memory; the kernel posts (seq | prefilter flag) << 32
 // | total with ONE system-scope release store -- payload and sequence number cannot be seen apart -- and the host,
 // polling that word, learns num_rendered without a stream synchronisation (seq is a multiple of 4, never 0; bit 0 = the
-// prefilter flag, bit 1 = "rows spatially coherent", see below).
+// prefilter flag, bit 1 = "bin the next forward by direct placement", see below).
 __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint32_t* __restrict__ block_sums,
                                                                uint32_t* __restrict__ block_offsets,
                                                                uint32_t* __restrict__ counters,
@@ -101,10 +101,13 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
         __syncthreads();
     }
-    // sum of the workgroups' tile rectangles (preprocess launch): an upper bound of the device-scope adds direct placement
-    // needs per phase (a loose one: C2's eight views give 0.45 of num_rendered where the adds that actually happen are
-    // ~0.1 of it, rows in no order give 1.0).  At most half of num_rendered: the rows count as spatially coherent, the NEXT forward of
-    // this thread bins by direct placement (api.hip); otherwise by the radix passes.
+    // block_area summed = the device-scope adds direct placement needs per phase: their exact number when this forward
+    // bins by direct placement (tile_cursor != null), an upper bound from the workgroups' tile rectangles otherwise (the
+    // adds that happen are ~0.6 of it at C2 and C4).  Whether the NEXT forward of the thread bins by direct placement
+    // (api.hip) follows the measured cost of the two ways on this chip (preprocess + scan + emission + sort at C2 / C3 / C4,
+    // DESIGN.md section 4): passes 71.5 us + 52 ps per instance, direct placement 25 us + 75 ps per instance + 152 ps per
+    // add -- the passes pay six more latency-bound launches, placement pays per instance and per add:
+    //     direct placement  <=>  num_rendered + 7 adds <= 2 100 000.
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) area += __shfl_xor(area, off, 64);
     if (lane == 0) s_area[wave] = area;
@@ -112,7 +115,8 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
     if (threadIdx.x == 0) {
         uint32_t area_sum = 0;
         for (int w = 0; w < 16; w++) area_sum += s_area[w];
-        const uint32_t compact = (s_carry != 0u && (unsigned long long)area_sum * 2ull <= (unsigned long long)s_carry) ? 2u : 0u;
+        const unsigned long long adds = tile_cursor ? (unsigned long long)area_sum : (unsigned long long)area_sum * 3ull / 5ull;
+        const uint32_t compact = (s_carry != 0u && (unsigned long long)s_carry + 7ull * adds <= 2100000ull) ? 2u : 0u;
         counters[0] = s_carry;
         counters[1] = any_flag ? 1u : 0u;
         counters[2] = compact;

@@ -91,7 +91,8 @@ struct GeomState {
     uint32_t* block_sums;     // [ceil(P/256)]
     uint32_t* block_offsets;  // [ceil(P/256)] exclusive scan of block_sums
     uint32_t* counters;       // [64] counters[0] = num_rendered, counters[1] = prefilter violation flag, counters[2] = 2 if
-                              // the rows are spatially coherent (scan_block_sums_kernel), else 0
+                              // the next forward should bin by direct placement (scan_block_sums_kernel), else 0;
+                              // counters[3] = the device-scope adds direct placement needs (exact / upper bound)
     uint32_t* block_area;     // [ceil(P/256)] tiles in the rectangle around the workgroup's Gaussians (preprocess launch)
     static GeomState from_chunk(char*& chunk, size_t P);
     static size_t required(size_t P);

@@ -192,14 +192,20 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     // LDS (four adds per Gaussian), then one device-scope add per tile it touches.
     if (tile_count == nullptr) return;                      // uniform
     __shared__ uint32_t s_bins[GS4D_AGG_BINS];
+    __shared__ uint32_t s_adds;
     const int tid = threadIdx.x, lane = tid & 63;
     const bool agg = any_small && bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;   // uniform
+    uint32_t adds = 0;                                      // device-scope adds of this lane: block_area becomes their exact number
+    if (tid == 0) s_adds = 0u;
     if (agg) {
         block_tile_counts(small, my_x0, my_y0, my_x1, my_y1, bx0, by0, bw, bh, s_bins);
         const int pitch = bw + 1, cells = pitch * bh;
         for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
             const uint32_t c = s_bins[b];
-            if (c) atomicAdd(&tile_count[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
+            if (c) {
+                atomicAdd(&tile_count[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
+                adds++;
+            }
         }
     }
     // one add per instance: the big splats (and everything, if the rows are in no spatial order), a wave per Gaussian
@@ -209,9 +215,17 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
         todo &= todo - 1ull;
         const int x0 = __shfl(my_x0, src, 64), y0 = __shfl(my_y0, src, 64), w = __shfl(my_x1, src, 64) - x0;
         const int n = (int)__shfl((int)my_tiles, src, 64);
-        for (int k = lane; k < n; k += 64)
+        for (int k = lane; k < n; k += 64) {
             atomicAdd(&tile_count[(size_t)((y0 + k / w) * gx + x0 + k % w) * GS4D_TILE_CURSOR_STRIDE], 1u);
+            adds++;
+        }
     }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) adds += __shfl_xor(adds, off, 64);
+    __syncthreads();                                        // s_adds = 0 (without the LDS counts no barrier came before)
+    if (lane == 0) atomicAdd(&s_adds, adds);
+    __syncthreads();
+    if (tid == 0) block_area[blockIdx.x] = s_adds;
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,

@@ -501,7 +501,7 @@ def main():
                                         # how the forwards were binned (include/gs4d.h: gs4d_binning_stats) and the last
                                         # forward's two numbers that the choice rests on
                                         "binning": {"direct_placement": bin1[0] - bin0[0], "radix_passes": bin1[1] - bin0[1],
-                                                    "last_rect_tiles": bin1[2], "last_rendered": bin1[3]},
+                                                    "last_adds": bin1[2], "last_rendered": bin1[3]},
                                         "hex_order": hex_order_counts()},
                        # memory of the per-view binning state (keys, values, sort buffers, histograms + the blend's segment
                        # checkpoints that only a training forward reserves), per rendered instance

@@ -154,14 +154,16 @@ void gs4d_forward_stats(unsigned long long* fast, unsigned long long* slow, unsi
 void gs4d_speculation_stats(unsigned long long* issued, unsigned long long* reissued);
 /* Forwards of the calling thread whose (Gaussian, tile) instances were binned by direct placement (*direct: counted per
  * tile during preprocessing and written straight into the tile lists, csrc/tile_place.h) and by the two stable radix
- * passes on the tile bits (*passes).  The lists are the same bit for bit; which one runs is decided per forward: direct
- * placement when the previous forward of the thread found the rows of the model in a spatially coherent order (the sum
- * of the tile rectangles around every 256 consecutive Gaussians is at most half of num_rendered), the passes
- * otherwise and on a thread's first forward.  GS4D_SORT=direct / tile forces one of them, GS4D_SORT=lsd selects the
- * six-pass sort of the whole key (no reference counterpart: the reference always runs the device-wide radix sort,
- * rasterizer_impl.cu:301-309).  *last_rect_tiles / *last_rendered: the two numbers of the thread's last forward that
- * the choice for the next one rests on.  Any pointer may be null. */
-void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes, unsigned long long* last_rect_tiles,
+ * passes on the tile bits (*passes).  The lists are the same bit for bit; which one runs is decided per forward from
+ * two numbers of the thread's PREVIOUS forward: num_rendered and the device-scope atomic adds direct placement needs per
+ * phase (one per tile that the Gaussians of a 256-row workgroup touch together: few when the rows of the model are in a
+ * spatially coherent order; exact when that forward placed directly, an upper bound from the workgroups' tile
+ * rectangles otherwise).  Direct placement runs when num_rendered + 7 adds <= 2 100 000 (the measured costs of the two
+ * ways on MI355X, csrc/binning.hip); a thread's first forward takes the passes.  GS4D_SORT=direct / tile forces one of
+ * them, GS4D_SORT=lsd selects the six-pass sort of the whole key (no reference counterpart: the reference always runs
+ * the device-wide radix sort, rasterizer_impl.cu:301-309).  *last_adds / *last_rendered: those two numbers of the
+ * thread's last forward.  Any pointer may be null. */
+void gs4d_binning_stats(unsigned long long* direct, unsigned long long* passes, unsigned long long* last_adds,
                         unsigned long long* last_rendered);
 
 /* present[i] = (view-space z of means3D[i]) > 0.2 ; rasterizer_impl.cu:54-66,141-153. `present` is device uint8/bool [P]. */

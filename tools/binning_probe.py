@@ -21,4 +21,4 @@ for order in (True, False):
             out = rd.render(sc["cam"], sc["pc"], sc["deform"], sc["bg"])
         torch.cuda.synchronize()
         radii = out[3]
-        print("spatial_order", order, "forward", i, "(direct, passes, rect tiles, rendered)", cabi.binning_stats_full(), "visible", int((radii > 0).sum()))
+        print("spatial_order", order, "forward", i, "(direct, passes, adds, rendered)", cabi.binning_stats_full(), "visible", int((radii > 0).sum()))
