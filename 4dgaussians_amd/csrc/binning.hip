@@ -106,8 +106,9 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
     // adds that happen are ~0.6 of it at C2 and C4).  Whether the NEXT forward of the thread bins by direct placement
     // (api.hip) follows the measured cost of the two ways on this chip (preprocess + scan + emission + sort at C2 / C3 / C4,
     // DESIGN.md section 4): passes 71.5 us + 52 ps per instance, direct placement 25 us + 75 ps per instance + 152 ps per
-    // add -- the passes pay six more latency-bound launches, placement pays per instance and per add:
-    //     direct placement  <=>  num_rendered + 7 adds <= 2 100 000.
+    // add -- the passes pay six more latency-bound launches, placement pays per instance and per add: break-even at
+    // num_rendered + 7 adds = 2.1 M with those figures, 2.4 M after the lists' (depth, index) words became one store:
+    //     direct placement  <=>  num_rendered + 7 adds <= 2 400 000.
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) area += __shfl_xor(area, off, 64);
     if (lane == 0) s_area[wave] = area;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
         uint32_t area_sum = 0;
         for (int w = 0; w < 16; w++) area_sum += s_area[w];
         const unsigned long long adds = tile_cursor ? (unsigned long long)area_sum : (unsigned long long)area_sum * 3ull / 5ull;
-        const uint32_t compact = (s_carry != 0u && (unsigned long long)s_carry + 7ull * adds <= 2100000ull) ? 2u : 0u;
+        const uint32_t compact = (s_carry != 0u && (unsigned long long)s_carry + 7ull * adds <= 2400000ull) ? 2u : 0u;
         counters[0] = s_carry;
         counters[1] = any_flag ? 1u : 0u;
         counters[2] = compact;
@@ -264,8 +265,10 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_keys_kernel(
 
 // ------------------------------------------------------------------ key emission with direct placement (GS4D_SORT=direct)
 // Same emission as emit_keys_kernel (keys / values in emission order are still written: gs4d_state_view_get shows them),
-// and every instance also goes straight into its tile's list: [tile_base[t], tile_base[t + 1]) of keys_tile /
-// values_tile, laid out by the scan launch from the counts of the preprocess launch.  A list is filled in arbitrary
+// and every instance also goes straight into its tile's list: [tile_base[t], tile_base[t + 1]) of keys_tile, laid out
+// by the scan launch from the counts of the preprocess launch, as ONE 8-byte word (depth bits low, Gaussian index high:
+// the tile is the list itself; a second scattered store for the index cost 12 MB of partial-sector writes at C2 --
+// segment_depth_sort_kernel<true> reads this form).  A list is filled in arbitrary
 // order -- the per-tile sort that follows orders it by depth, then Gaussian index.  Positions are handed out in two
 // levels (tile_place.h): the workgroup counts its Gaussians per tile of its rectangle in LDS, takes one run of positions
 // per tile from the tile's cursor (one device-scope add per tile it touches) and leaves the run's start in the tile's LDS
@@ -276,8 +279,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
     const uint32_t* __restrict__ block_offsets, uint32_t* __restrict__ point_offsets,
     uint64_t* __restrict__ keys, uint32_t* __restrict__ values, uint2* __restrict__ ranges, int ntiles,
     uint2* __restrict__ seg_owner, int seg_slots, uint32_t cap, const uint32_t* __restrict__ R_dev,
-    uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_base, uint64_t* __restrict__ keys_tile,
-    uint32_t* __restrict__ values_tile)
+    uint32_t* __restrict__ tile_cursor, const uint32_t* __restrict__ tile_base, uint64_t* __restrict__ keys_tile)
 {
     // speculative launch with more instances than it was sized for: the tiles stay empty, nothing is emitted (the cursors
     // stay where the scan launch put them: the re-issued launch finds them)
@@ -374,8 +376,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
             if (q == 1 && !second) break;
             keys[base + sv[q]] = key[q];
             values[base + sv[q]] = val[q];
-            keys_tile[at[q]] = key[q];
-            values_tile[at[q]] = val[q];
+            keys_tile[at[q]] = ((uint64_t)val[q] << 32) | (key[q] & 0xffffffffull);   // (depth bits, Gaussian): ONE scattered store
         }
     }
 }
@@ -707,8 +708,14 @@ __device__ __forceinline__ void wave_sort_list(WaveSeg& S, uint32_t begin, int n
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int pos = min(r * 64 + lane, n - 1);
-        k[r] = (uint32_t)keys_a[begin + pos];
-        v[r] = vals_a[begin + pos];
+        if (TIES) {                                           // direct placement's lists: (depth bits, Gaussian) in one word
+            const uint64_t kv = keys_a[begin + pos];
+            k[r] = (uint32_t)kv;
+            v[r] = (uint32_t)(kv >> 32);
+        } else {
+            k[r] = (uint32_t)keys_a[begin + pos];
+            v[r] = vals_a[begin + pos];
+        }
     }
     const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)k[0]);
     uint32_t diff = 0;
@@ -835,8 +842,14 @@ __device__ __forceinline__ void wg_sort_list(SegShared& S, uint32_t begin, int n
 #pragma unroll
     for (int r = 0; r < R; r++) {
         const int pos = min(base + r * 64 + lane, n - 1);
-        k[r] = (uint32_t)keys_a[begin + pos];
-        v[r] = vals_a[begin + pos];
+        if (TIES) {
+            const uint64_t kv = keys_a[begin + pos];
+            k[r] = (uint32_t)kv;
+            v[r] = (uint32_t)(kv >> 32);
+        } else {
+            k[r] = (uint32_t)keys_a[begin + pos];
+            v[r] = vals_a[begin + pos];
+        }
     }
     const uint32_t key0 = (uint32_t)keys_a[begin];
     uint32_t diff = 0;
@@ -1018,7 +1031,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             const int rounds = (cn + 255) >> 8;
             for (int i = tid; i < cn; i += 256) {
                 S.k[0][i] = (uint32_t)kin[c0 + i];
-                S.v[0][i] = vin[c0 + i];
+                S.v[0][i] = (TIES && pass == 0) ? (uint32_t)(kin[c0 + i] >> 32) : vin[c0 + i];   // pass 0 of direct placement: packed lists
             }
             __syncthreads();
             seg_rank_chunk(S, S.k[0], rounds, cn, shift, false);
@@ -1123,7 +1136,7 @@ int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState&
         hipLaunchKernelGGL(emit_place_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                            radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,
                            im.ranges, gx * gy, b.seg_owner, b.seg_owner ? (int)b.seg_slots : 0, (uint32_t)R, R_dev,
-                           im.tile_cursor, im.tile_base, b.keys_tmp[half_in], b.values_tmp[half_in]);
+                           im.tile_cursor, im.tile_base, b.keys_tmp[half_in]);
     else
     hipLaunchKernelGGL(emit_keys_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, gx, gy, g.means2D, g.depths,
                        radii, g.tiles_touched, g.block_offsets, g.point_offsets, b.keys_unsorted, b.values_unsorted,

@@ -158,7 +158,7 @@ void gs4d_speculation_stats(unsigned long long* issued, unsigned long long* reis
  * two numbers of the thread's PREVIOUS forward: num_rendered and the device-scope atomic adds direct placement needs per
  * phase (one per tile that the Gaussians of a 256-row workgroup touch together: few when the rows of the model are in a
  * spatially coherent order; exact when that forward placed directly, an upper bound from the workgroups' tile
- * rectangles otherwise).  Direct placement runs when num_rendered + 7 adds <= 2 100 000 (the measured costs of the two
+ * rectangles otherwise).  Direct placement runs when num_rendered + 7 adds <= 2 400 000 (the measured costs of the two
  * ways on MI355X, csrc/binning.hip); a thread's first forward takes the passes.  GS4D_SORT=direct / tile forces one of
  * them, GS4D_SORT=lsd selects the six-pass sort of the whole key (no reference counterpart: the reference always runs
  * the device-wide radix sort, rasterizer_impl.cu:301-309).  *last_adds / *last_rendered: those two numbers of the

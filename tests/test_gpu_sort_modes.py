@@ -44,7 +44,7 @@ def test_sort_strategies_agree_bit_for_bit():
 
 def test_binning_follows_the_row_order_of_the_model():
     """Unforced (GS4D_SORT unset), the forward bins by direct placement when the counts of the PREVIOUS forward of the thread
-    say it is cheaper (scan_block_sums_kernel: num_rendered + 7 x the device-scope adds placement needs <= 2.1 M; the adds
+    say it is cheaper (scan_block_sums_kernel: num_rendered + 7 x the device-scope adds placement needs <= 2.4 M; the adds
     are few when every 256 consecutive rows touch few tiles together), by the radix passes otherwise: i.i.d. rows stay on
     the passes, the same Gaussians in Morton order switch after one forward, and both give the same lists and image bit
     for bit."""
