@@ -256,6 +256,11 @@ bool gs4d_sort_tile_first()
     return v;
 }
 
+bool gs4d_forward_bins_directly()
+{
+    return gs4d_sort_tile_first() && (gs4d_sort_direct_forced() >= 0 ? gs4d_sort_direct_forced() == 1 : t_state.direct_next);
+}
+
 int gs4d_sort_direct_forced()
 {
     static const int v = [] { const char* e = getenv("GS4D_SORT"); return !e || !e[0] ? -1 : (e[0] == 'd' ? 1 : 0); }();
@@ -443,11 +448,13 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     // How this forward bins its instances: by direct placement (csrc/tile_place.h) when the counts of the previous forward
     // of this thread say it is the cheaper way (few instances, rows in a spatially coherent order: scan_block_sums_kernel;
     // or GS4D_SORT=direct), by the radix passes on the tile bits otherwise (GS4D_SORT=tile: always).  Same lists either way, bit for bit, in the same half of the binning chunk.
-    const bool direct = gs4d_sort_tile_first() && (gs4d_sort_direct_forced() >= 0 ? gs4d_sort_direct_forced() == 1 : t_state.direct_next);
+    const bool direct = gs4d_forward_bins_directly();
+    const bool counters_cleared = (speculate & 2) != 0;     // the caller's previous launch cleared im.tile_cursor (csrc/render.hip)
+    speculate &= 1;
     int rc = gs4d_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height,
                                     tan_fovx, tan_fovy, prefiltered, radii, g, debug, s,
-                                    direct ? im.tile_cursor : nullptr);
+                                    direct ? im.tile_cursor : nullptr, counters_cleared);
     if (rc) return rc;
     // The one host round trip of the forward (rasterizer_impl.cu:282): num_rendered sizes the binning chunk.  The scan
     // kernel posts ONE 64-bit word (sequence | prefilter flag, num_rendered) into a pinned, coherent host mailbox and the

@@ -23,8 +23,12 @@ __global__ __launch_bounds__(256) void activate_forward_kernel(int P, const floa
                                                                const float4* __restrict__ rot,
                                                                const float* __restrict__ opacity_logit,
                                                                float* __restrict__ scales, float4* __restrict__ rot_n,
-                                                               float* __restrict__ opacity)
+                                                               float* __restrict__ opacity, uint32_t* __restrict__ clear,
+                                                               unsigned clear_words)
 {
+    // the composite render call (csrc/render.hip) lets this launch, the one in front of the preprocess launch, clear the
+    // per-tile counters of the binning by direct placement: a memset node of its own costs 5 us
+    for (unsigned w = blockIdx.x * 256u + threadIdx.x; w < clear_words; w += gridDim.x * 256u) clear[w] = 0u;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
 #pragma unroll
@@ -143,6 +147,14 @@ extern "C" {
 int gs4d_activate_forward(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
                           float* scales, float* rotations_n, float* opacity, void* stream)
 {
+    return gs4d_activate_forward_clear(P, log_scales, rotations, opacity_logit, scales, rotations_n, opacity, nullptr, 0, stream);
+}
+
+}  // extern "C"
+int gs4d_activate_forward_clear(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
+                                float* scales, float* rotations_n, float* opacity, uint32_t* clear, size_t clear_words,
+                                void* stream)
+{
     GS4D_TRACE_SCOPE("gs4d_activate_forward");
     if (P == 0) return GS4D_OK;
     if (P < 0 || !log_scales || !rotations || !opacity_logit || !scales || !rotations_n || !opacity ||
@@ -152,11 +164,13 @@ int gs4d_activate_forward(int P, const float* log_scales, const float* rotations
     }
     hipStream_t s = (hipStream_t)stream;
     GS4D_PROF("activate_forward", s);
+    if (clear_words > 0xffffffffull) { gs4d_set_error("gs4d_activate_forward: clear range too large"); return GS4D_EINVAL; }
     hipLaunchKernelGGL(activate_forward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, log_scales,
-                       (const float4*)rotations, opacity_logit, scales, (float4*)rotations_n, opacity);
+                       (const float4*)rotations, opacity_logit, scales, (float4*)rotations_n, opacity, clear, (unsigned)clear_words);
     GS4D_LAUNCH_CHECK("activate_forward", 0, s);
     return GS4D_OK;
 }
+extern "C" {
 
 int gs4d_activate_backward(int P, const float* scales, const float* rotations, const float* opacity,
                            const float* g_scales, const float* g_rotations_n, const float* g_opacity,

@@ -153,6 +153,13 @@ bool gs4d_sort_tile_first();
 // GS4D_SORT=direct / tile: counted placement into the tile lists (csrc/tile_place.h) always / never; unset: per forward,
 // decided by what the previous forward of the thread measured.  -1 = not forced, 0 = never, 1 = always.
 int gs4d_sort_direct_forced();
+// csrc/api.hip: will the calling thread's next forward bin by direct placement?  (the composite call clears the per-tile
+// counters in its activation launch then: gs4d_rasterize_forward_spec's `speculate` bit 1)
+bool gs4d_forward_bins_directly();
+// csrc/elementwise.hip: gs4d_activate_forward that also zeroes clear[0 .. clear_words)
+int gs4d_activate_forward_clear(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
+                                float* scales, float* rotations_n, float* opacity, uint32_t* clear, size_t clear_words,
+                                void* stream);
 uint32_t gs4d_sort_segment_cap();
 uint32_t gs4d_sort_wave_cap();
 int gs4d_radix_sort_pairs(uint32_t R, int passes, int first_shift, const uint64_t* keys_in, const uint32_t* vals_in,
@@ -165,7 +172,7 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
                            float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s,
-                           uint32_t* tile_count = nullptr);
+                           uint32_t* tile_count = nullptr, bool tile_count_cleared = false);
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 // csrc/api.hip: the rasterizer entry points with the speculative binning launch / an explicit binning layout (csrc/render.hip)
 int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,

@@ -246,14 +246,14 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
                            float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s,
-                           uint32_t* tile_count)
+                           uint32_t* tile_count, bool tile_count_cleared)
 {
     GS4D_PROF("preprocess", s);
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (H + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
-    if (tile_count) GS4D_HIP_CHECK(hipMemsetAsync(tile_count, 0, (size_t)gx * gy * GS4D_TILE_CURSOR_STRIDE * sizeof(uint32_t), s));
+    if (tile_count && !tile_count_cleared) GS4D_HIP_CHECK(hipMemsetAsync(tile_count, 0, (size_t)gx * gy * GS4D_TILE_CURSOR_STRIDE * sizeof(uint32_t), s));
     hipLaunchKernelGGL(preprocess_kernel, dim3(nblk), dim3(GS4D_PRE_BLOCK), 0, s, P, D, M, means3D, scales,
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                        projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, prefiltered, radii,

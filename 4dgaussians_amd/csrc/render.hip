@@ -171,7 +171,19 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
         if (rc) return rc;
         m3 = a.m3; sc = a.sc; rot = a.rot; shs = a.shs;
     }
-    rc = gs4d_activate_forward(r->P, sc, rot, r->opacity_logit, a.scales_a, a.rot_n, a.opacity_a, stream);
+    // a forward that bins by direct placement needs its per-tile counters cleared in front of the preprocess launch: the
+    // activation launch does it on the way (the image chunk is part of the arena, so its place is known already)
+    uint32_t* tile_counters = nullptr;
+    size_t tile_counter_words = 0;
+    if (gs4d_forward_bins_directly()) {
+        const size_t gx = (r->width + GS4D_TILE_X - 1) / GS4D_TILE_X, gy = (r->height + GS4D_TILE_Y - 1) / GS4D_TILE_Y;
+        char* ic = a.image;
+        const ImageState im = ImageState::from_chunk(ic, (size_t)r->width * r->height, gx * gy);
+        tile_counters = im.tile_cursor;
+        tile_counter_words = gx * gy * GS4D_TILE_CURSOR_STRIDE;
+    }
+    rc = gs4d_activate_forward_clear(r->P, sc, rot, r->opacity_logit, a.scales_a, a.rot_n, a.opacity_a, tile_counters,
+                                     tile_counter_words, stream);
     if (rc) return rc;
     FixedBlock geom{a.geom, a.geom_bytes}, image{a.image, a.image_bytes};
     BinningRelay bin{alloc, alloc_ctx, nullptr, 0};
@@ -181,7 +193,8 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
     rc = gs4d_rasterize_forward_spec(fixed_alloc, &geom, binning_alloc, &bin, fixed_alloc, &image, r->P, r->D, r->M,
                                      r->background, r->width, r->height, m3, shs, nullptr, a.opacity_a, a.scales_a,
                                      r->scale_modifier, a.rot_n, nullptr, r->viewmatrix, r->projmatrix, r->cam_pos, r->tan_fovx,
-                                     r->tan_fovy, r->prefiltered, out_color, out_depth, radii, r->flags, stream, &R, 1, &layout_R);
+                                     r->tan_fovy, r->prefiltered, out_color, out_depth, radii, r->flags, stream, &R,
+                                     1 | (tile_counters ? 2 : 0), &layout_R);
     state->binning = bin.last;
     state->binning_bytes = bin.last_bytes;
     state->num_rendered = R;
