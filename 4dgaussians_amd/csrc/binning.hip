@@ -48,7 +48,7 @@ __device__ __forceinline__ uint32_t resolve_R(uint32_t R_host, const uint32_t* _
     return r > R_host ? GS4D_R_OVERFLOW : r;
 }
 
-// ------------------------------------------------------------------ block-sum scan (1 workgroup)
+// ------------------------------------------------------------------ block-sum scan (1 workgroup; direct placement: a second one lays out the tile lists)
 // block_offsets = exclusive scan of block_sums (bits 0..30; bit 31 is the workgroup's prefilter flag); counters[0] =
 // total, counters[1] = OR of the flags (both words are written here: nothing clears them).  n is ceil(P/256)
 // (391 at P = 100k, 19.5k at P = 5M), so one 1024-lane workgroup looping over chunks is enough.
@@ -69,12 +69,46 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) s_carry = 0;
-    // direct placement: the first 4 096 per-tile counts (four consecutive tiles per lane) are requested now, their latency
-    // passes behind the scan of the block sums
-    uint32_t c[4] = {0u, 0u, 0u, 0u};
-    if (tile_cursor) {
+    if (blockIdx.x == 1) {
+        // Direct placement, second workgroup of the launch (beside the block sums, not behind them): tile_cursor holds the
+        // instances per tile (counted by the preprocess launch); their exclusive scan is where each tile's list starts.
+        // tile_base keeps it (the ranges), tile_cursor becomes the list's write cursor.  Four consecutive tiles per lane.
+        __syncthreads();
+        for (int base = 0; base < ntiles; base += 4096) {
+            const int i0 = base + 4 * (int)threadIdx.x;
+            uint32_t c[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) c[q] = tile_cursor[(size_t)min(4 * (int)threadIdx.x + q, ntiles - 1) * GS4D_TILE_CURSOR_STRIDE];
+            for (int q = 0; q < 4; q++) c[q] = tile_cursor[(size_t)min(i0 + q, ntiles - 1) * GS4D_TILE_CURSOR_STRIDE];
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (i0 + q >= ntiles) c[q] = 0u;
+            const uint32_t v = c[0] + c[1] + c[2] + c[3];
+            uint32_t incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            if (lane == 63) s_wave[wave] = incl;
+            __syncthreads();
+            uint32_t wave_prefix = 0;
+            for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
+            const uint32_t carry = s_carry;
+            uint32_t run = carry + wave_prefix + incl - v;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (i0 + q < ntiles) {
+                    tile_base[i0 + q] = run;
+                    tile_cursor[(size_t)(i0 + q) * GS4D_TILE_CURSOR_STRIDE] = run;
+                }
+                run += c[q];
+            }
+            __syncthreads();
+            if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) tile_base[ntiles] = s_carry;
+        return;
     }
     __syncthreads();
     int flag = 0;
@@ -128,48 +162,6 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
             __hip_atomic_store(mailbox, word, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    // Direct placement: tile_cursor holds the instances per tile (counted by the preprocess launch); their exclusive scan
-    // is where each tile's list starts.  tile_base keeps it (the ranges), tile_cursor becomes the list's write cursor.
-    // After the post: the host does not wait for this part.
-    if (tile_cursor == nullptr) return;                  // uniform
-    __syncthreads();
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (int base = 0; base < ntiles; base += 4096) {
-        const int i0 = base + 4 * (int)threadIdx.x;
-        if (base) {
-#pragma unroll
-            for (int q = 0; q < 4; q++) c[q] = tile_cursor[(size_t)min(i0 + q, ntiles - 1) * GS4D_TILE_CURSOR_STRIDE];
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (i0 + q >= ntiles) c[q] = 0u;
-        const uint32_t v = c[0] + c[1] + c[2] + c[3];
-        uint32_t incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t wave_prefix = 0;
-        for (int w = 0; w < wave; w++) wave_prefix += s_wave[w];
-        const uint32_t carry = s_carry;
-        uint32_t run = carry + wave_prefix + incl - v;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            if (i0 + q < ntiles) {
-                tile_base[i0 + q] = run;
-                tile_cursor[(size_t)(i0 + q) * GS4D_TILE_CURSOR_STRIDE] = run;
-            }
-            run += c[q];
-        }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_prefix + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) tile_base[ntiles] = s_carry;
 }
 
 // ------------------------------------------------------------------ key emission
@@ -1116,7 +1108,7 @@ int gs4d_launch_scan(int P, GeomState& g, unsigned long long* mailbox, uint32_t 
 {
     GS4D_PROF("scan", s);
     const int nblk = (P + GS4D_PRE_BLOCK - 1) / GS4D_PRE_BLOCK;
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(1), dim3(1024), 0, s, nblk, g.block_sums, g.block_offsets,
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3(tile_cursor ? 2 : 1), dim3(1024), 0, s, nblk, g.block_sums, g.block_offsets,
                        g.counters, mailbox, seq, g.block_area, tile_cursor, tile_base, ntiles);
     GS4D_LAUNCH_CHECK("scan_block_sums", debug, s);
     return GS4D_OK;
