@@ -190,7 +190,7 @@ GeomState GeomState::from_chunk(char*& chunk, size_t P)
     gs4d_obtain(chunk, g.block_sums, nblk);
     gs4d_obtain(chunk, g.block_offsets, nblk);
     gs4d_obtain(chunk, g.counters, 64);
-    gs4d_obtain(chunk, g.block_area, nblk);
+    gs4d_obtain(chunk, g.block_area, 4 * nblk);
     return g;
 }
 

@@ -116,7 +116,10 @@ __global__ __launch_bounds__(1024) void scan_block_sums_kernel(int n, const uint
     for (int base = 0; base < n; base += 1024) {
         const int i = base + threadIdx.x;
         const uint32_t raw = i < n ? block_sums[i] : 0u;
-        area += i < n ? block_area[i] : 0u;
+        if (i < n) {
+            const uint4 a4 = reinterpret_cast<const uint4*>(block_area)[i];     // the workgroup's four per-wave words
+            area += a4.x + a4.y + a4.z + a4.w;
+        }
         const uint32_t v = raw & 0x7fffffffu;
         flag |= (int)(raw >> 31);
         uint32_t incl = v;
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
     __shared__ uint32_t s_wave[GS4D_PRE_BLOCK / 64];
     __shared__ int s_x0[GS4D_PRE_BLOCK], s_y0[GS4D_PRE_BLOCK], s_w[GS4D_PRE_BLOCK];
     __shared__ uint32_t s_depth[GS4D_PRE_BLOCK];
-    __shared__ uint32_t s_bins[GS4D_AGG_BINS];
+    __shared__ __align__(16) uint32_t s_bins[GS4D_AGG_BINS];
     __shared__ int s_red[GS4D_PRE_BLOCK / 64][6];
     __shared__ uint8_t s_big[GS4D_PRE_BLOCK];
 
@@ -318,6 +321,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void emit_place_kernel(
         if (lane >= off) incl += t;
     }
     if (lane == 63) s_wave[wave] = incl;
+    block_tile_clear(s_bins);                                // in front of the barrier inside block_tile_bbox()
     // the same split as in the preprocess launch: big splats apart, the others inside the workgroup's rectangle
     const bool big = cnt != 0u && tile_rect_is_big(x0, y0, x1, y1);
     const bool small = cnt != 0u && !big;

@@ -93,7 +93,8 @@ struct GeomState {
     uint32_t* counters;       // [64] counters[0] = num_rendered, counters[1] = prefilter violation flag, counters[2] = 2 if
                               // the next forward should bin by direct placement (scan_block_sums_kernel), else 0;
                               // counters[3] = the device-scope adds direct placement needs (exact / upper bound)
-    uint32_t* block_area;     // [ceil(P/256)] tiles in the rectangle around the workgroup's Gaussians (preprocess launch)
+    uint32_t* block_area;     // [ceil(P/256)][4 waves] the device-scope adds direct placement needs for the workgroup: exact,
+                              // or an upper bound from the rectangle of tiles around its Gaussians (preprocess launch)
     static GeomState from_chunk(char*& chunk, size_t P);
     static size_t required(size_t P);
 };

@@ -72,6 +72,9 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     uint32_t my_tiles = 0;
     int my_radius_i = 0;
     int my_x0 = 0, my_y0 = 0, my_x1 = 1, my_y1 = 1;
+    float my_depth = 0.f;
+    float2 my_mean = make_float2(0.f, 0.f);
+    float4 my_conic = make_float4(0.f, 0.f, 0.f, 0.f);
     int bad = 0;
     // Every input of the Gaussian is requested up front, before the first test that could skip it: under the near-plane /
     // empty-rectangle branches the scales, the rotation, the opacity and the 48 SH floats were three memory latencies in
@@ -133,22 +136,11 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
                 tile_rect(pix_x, pix_y, (int)my_radius, gx, gy, x0, y0, x1, y1);
                 const uint32_t ntiles = (uint32_t)(x1 - x0) * (uint32_t)(y1 - y0);
                 if (ntiles != 0) {
-                    if (colors_precomp == nullptr) {
-                        float3 dir = make_float3(p_orig.x - s_cam[0], p_orig.y - s_cam[1], p_orig.z - s_cam[2]);
-                        const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
-                        dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
-                        bool neg[3];
-                        const float3 col = sh_regs ? sh_to_rgb(D, sh_in, dir, neg) : sh_to_rgb(D, shs + (size_t)idx * M * 3, dir, neg);
-                        rgb[3 * (size_t)idx + 0] = col.x;
-                        rgb[3 * (size_t)idx + 1] = col.y;
-                        rgb[3 * (size_t)idx + 2] = col.z;
-                        clamped[3 * (size_t)idx + 0] = neg[0];
-                        clamped[3 * (size_t)idx + 1] = neg[1];
-                        clamped[3 * (size_t)idx + 2] = neg[2];
-                    }
-                    depths[idx] = p_view.z;
-                    means2D[idx] = make_float2(pix_x, pix_y);
-                    conic_opacity[idx] = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, op_in);
+                    // the colour and the per-Gaussian stores come LAST (below): the tile rectangle is all the counting of
+                    // the direct placement needs, and its device-scope adds retire while the colour is evaluated
+                    my_depth = p_view.z;
+                    my_mean = make_float2(pix_x, pix_y);
+                    my_conic = make_float4(cz * det_inv, -cy * det_inv, cx * det_inv, op_in);
                     my_radius_i = (int)my_radius;
                     my_tiles = ntiles;
                     my_x0 = x0; my_y0 = y0; my_x1 = x1; my_y1 = y1;
@@ -180,52 +172,71 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     // most: one per tile of the rectangle or per instance of a Gaussian in it, whichever is fewer, + one per instance of a
     // big splat.  The scan launch adds them up and tells the host whether direct placement pays (binning.hip, api.hip).
     __shared__ int s_red[GS4D_PRE_BLOCK / 64][6];
+    __shared__ __align__(16) uint32_t s_bins[GS4D_AGG_BINS];
+    if (tile_count != nullptr) block_tile_clear(s_bins);    // uniform; the barrier inside block_tile_bbox() follows
     const bool big = my_tiles != 0u && tile_rect_is_big(my_x0, my_y0, my_x1, my_y1);
     const bool small = my_tiles != 0u && !big;
     int bx0, by0, bw, bh;
     uint32_t small_tiles = small ? my_tiles : 0u, big_tiles = big ? my_tiles : 0u;
     const bool any_small = block_tile_bbox(small, my_x0, my_y0, my_x1, my_y1, s_red, bx0, by0, bw, bh, small_tiles, big_tiles);   // barrier inside
-    if (threadIdx.x == 0) block_area[blockIdx.x] = (any_small ? min((uint32_t)(bw * bh), small_tiles) : 0u) + big_tiles;
+    // (one word per wave: the exact count below needs no workgroup sum then)
+    if ((threadIdx.x & 63) == 0)
+        block_area[4 * blockIdx.x + (threadIdx.x >> 6)] = threadIdx.x == 0 ? (any_small ? min((uint32_t)(bw * bh), small_tiles) : 0u) + big_tiles : 0u;
 
     // Direct placement (tile_place.h): the (Gaussian, tile) instances are counted per tile here, so that the scan launch can
     // lay the tile lists out before the keys exist: counts of the workgroup's own Gaussians over its rectangle of tiles in
     // LDS (four adds per Gaussian), then one device-scope add per tile it touches.
-    if (tile_count == nullptr) return;                      // uniform
-    __shared__ uint32_t s_bins[GS4D_AGG_BINS];
-    __shared__ uint32_t s_adds;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const bool agg = any_small && bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;   // uniform
-    uint32_t adds = 0;                                      // device-scope adds of this lane: block_area becomes their exact number
-    if (tid == 0) s_adds = 0u;
-    if (agg) {
-        block_tile_counts(small, my_x0, my_y0, my_x1, my_y1, bx0, by0, bw, bh, s_bins);
-        const int pitch = bw + 1, cells = pitch * bh;
-        for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
-            const uint32_t c = s_bins[b];
-            if (c) {
-                atomicAdd(&tile_count[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
+    if (tile_count != nullptr) {                            // uniform
+        const int tid = threadIdx.x, lane = tid & 63;
+        const bool agg = any_small && bw < GS4D_AGG_SIDE && bh < GS4D_AGG_SIDE;   // uniform
+        uint32_t adds = 0;                                  // device-scope adds of this lane: block_area becomes their exact number
+        if (agg) {
+            block_tile_counts(small, my_x0, my_y0, my_x1, my_y1, bx0, by0, bw, bh, s_bins);
+            const int pitch = bw + 1, cells = pitch * bh;
+            for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) {
+                const uint32_t c = s_bins[b];
+                if (c) {
+                    atomicAdd(&tile_count[(size_t)((by0 + b / pitch) * gx + bx0 + b % pitch) * GS4D_TILE_CURSOR_STRIDE], c);
+                    adds++;
+                }
+            }
+        }
+        // one add per instance: the big splats (and everything, if the rows are in no spatial order), a wave per Gaussian
+        unsigned long long todo = __ballot(agg ? big : my_tiles != 0u);
+        while (todo) {
+            const int src = __ffsll(todo) - 1;
+            todo &= todo - 1ull;
+            const int x0 = __shfl(my_x0, src, 64), y0 = __shfl(my_y0, src, 64), w = __shfl(my_x1, src, 64) - x0;
+            const int n = (int)__shfl((int)my_tiles, src, 64);
+            for (int k = lane; k < n; k += 64) {
+                atomicAdd(&tile_count[(size_t)((y0 + k / w) * gx + x0 + k % w) * GS4D_TILE_CURSOR_STRIDE], 1u);
                 adds++;
             }
         }
-    }
-    // one add per instance: the big splats (and everything, if the rows are in no spatial order), a wave per Gaussian
-    unsigned long long todo = __ballot(agg ? big : my_tiles != 0u);
-    while (todo) {
-        const int src = __ffsll(todo) - 1;
-        todo &= todo - 1ull;
-        const int x0 = __shfl(my_x0, src, 64), y0 = __shfl(my_y0, src, 64), w = __shfl(my_x1, src, 64) - x0;
-        const int n = (int)__shfl((int)my_tiles, src, 64);
-        for (int k = lane; k < n; k += 64) {
-            atomicAdd(&tile_count[(size_t)((y0 + k / w) * gx + x0 + k % w) * GS4D_TILE_CURSOR_STRIDE], 1u);
-            adds++;
-        }
-    }
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) adds += __shfl_xor(adds, off, 64);
-    __syncthreads();                                        // s_adds = 0 (without the LDS counts no barrier came before)
-    if (lane == 0) atomicAdd(&s_adds, adds);
-    __syncthreads();
-    if (tid == 0) block_area[blockIdx.x] = s_adds;
+        for (int off = 32; off >= 1; off >>= 1) adds += __shfl_xor(adds, off, 64);
+        if (lane == 0) block_area[4 * blockIdx.x + (tid >> 6)] = adds;
+    }
+
+    // colour (forward.cu:161-207: same arithmetic, same order) and the per-Gaussian records of the Gaussians that touch a tile
+    if (my_tiles != 0u) {
+        if (colors_precomp == nullptr) {
+            float3 dir = make_float3(p_in.x - s_cam[0], p_in.y - s_cam[1], p_in.z - s_cam[2]);
+            const float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+            dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+            bool neg[3];
+            const float3 col = sh_regs ? sh_to_rgb(D, sh_in, dir, neg) : sh_to_rgb(D, shs + (size_t)idx * M * 3, dir, neg);
+            rgb[3 * (size_t)idx + 0] = col.x;
+            rgb[3 * (size_t)idx + 1] = col.y;
+            rgb[3 * (size_t)idx + 2] = col.z;
+            clamped[3 * (size_t)idx + 0] = neg[0];
+            clamped[3 * (size_t)idx + 1] = neg[1];
+            clamped[3 * (size_t)idx + 2] = neg[2];
+        }
+        depths[idx] = my_depth;
+        means2D[idx] = my_mean;
+        conic_opacity[idx] = my_conic;
+    }
 }
 
 __global__ __launch_bounds__(256) void mark_visible_kernel(int P, const float* __restrict__ means3D,

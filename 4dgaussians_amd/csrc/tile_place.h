@@ -76,17 +76,25 @@ __device__ __forceinline__ bool block_tile_bbox(bool has, int x0, int y0, int x1
     return true;
 }
 
+// Clears the cells block_tile_counts() works on; call it early (the rectangle is not known yet, so all of them: 16 words
+// per lane) and in front of a workgroup barrier.
+__device__ __forceinline__ void block_tile_clear(uint32_t* s_bins)
+{
+    uint4* z = reinterpret_cast<uint4*>(s_bins);
+#pragma unroll
+    for (int b = 0; b < GS4D_AGG_BINS / 4 / GS4D_PRE_BLOCK; b++) z[b * GS4D_PRE_BLOCK + threadIdx.x] = make_uint4(0u, 0u, 0u, 0u);
+}
+
 // Gaussians of the workgroup per tile of its rectangle (bw, bh <= GS4D_AGG_SIDE - 1): on return s_bins[y * (bw + 1) + x]
 // = number of lanes whose rectangle holds tile (bx0 + x, by0 + y); the guard column x = bw and row y = bh hold 0.
-// s_bins: GS4D_AGG_BINS words.  2-D difference array (unsigned wrap-around stands in for the -1), prefix along x with one
-// wave per row, along y with one wave per column.  Ends with a workgroup barrier.
+// s_bins: GS4D_AGG_BINS words, ALL ZERO on entry and that visible to the workgroup (block_tile_clear() in front of the
+// barrier inside block_tile_bbox()).  2-D difference array (unsigned wrap-around stands in for the -1), prefix along x
+// with one wave per row, along y with one wave per column.  Ends with a workgroup barrier.
 __device__ __forceinline__ void block_tile_counts(bool has, int x0, int y0, int x1, int y1, int bx0, int by0, int bw, int bh,
                                                   uint32_t* s_bins)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int pitch = bw + 1, cells = pitch * (bh + 1);
-    for (int b = tid; b < cells; b += GS4D_PRE_BLOCK) s_bins[b] = 0u;
-    __syncthreads();
+    const int pitch = bw + 1;
     if (has) {
         const int ax = x0 - bx0, ay = y0 - by0, cx = x1 - bx0, cy = y1 - by0;
         atomicAdd(&s_bins[ay * pitch + ax], 1u);
