@@ -304,7 +304,7 @@ extern "C" {
 
 const char* gs4d_last_error(void) { return g_err; }
 unsigned long long gs4d_debug_alloc_calls(void) { return g_alloc_calls.load(std::memory_order_relaxed); }
-int gs4d_abi_version(void) { return 12; }
+int gs4d_abi_version(void) { return 13; }
 
 void gs4d_thread_state_release(void)
 {

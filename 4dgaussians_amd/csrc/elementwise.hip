@@ -85,10 +85,17 @@ __device__ __forceinline__ float block_sum_256(float v, float* s)
     return s[0];
 }
 
+// g_scale / d_a (both or neither): the launch also writes d(g * mean |a - b|)/da = g sign(a - b) / n, element for element
+// what l1_backward_kernel computes (a training step knows g before its forward: csrc/render.hip)
+template <bool GRAD>
 __global__ __launch_bounds__(256) void l1_partial_kernel(size_t n, const float* __restrict__ a, const float* __restrict__ b,
-                                                         float* __restrict__ partial)
+                                                         float* __restrict__ partial, const float* __restrict__ g_scale,
+                                                         float* __restrict__ d_a)
 {
     __shared__ float s[256];
+    const float k = GRAD ? g_scale[0] / (float)n : 0.f;
+    auto sgn = [k](float d) { return d > 0.f ? k : (d < 0.f ? -k : 0.f); };
+    float4* __restrict__ d4 = reinterpret_cast<float4*>(d_a);
     // float4 rows, two per trip, four independent partial sums per lane (fixed order: deterministic); the callers' tensors
     // are 16-byte aligned (checked by the entry point), the last n % 4 elements go to one lane
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
@@ -98,6 +105,10 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(size_t n, const float* 
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (; i + stride < n4; i += 2 * stride) {
         const float4 x0 = a4[i], y0 = b4[i], x1 = a4[i + stride], y1 = b4[i + stride];
+        if (GRAD) {
+            d4[i] = make_float4(sgn(x0.x - y0.x), sgn(x0.y - y0.y), sgn(x0.z - y0.z), sgn(x0.w - y0.w));
+            d4[i + stride] = make_float4(sgn(x1.x - y1.x), sgn(x1.y - y1.y), sgn(x1.z - y1.z), sgn(x1.w - y1.w));
+        }
         acc0 += fabsf(x0.x - y0.x) + fabsf(x1.x - y1.x);
         acc1 += fabsf(x0.y - y0.y) + fabsf(x1.y - y1.y);
         acc2 += fabsf(x0.z - y0.z) + fabsf(x1.z - y1.z);
@@ -105,10 +116,14 @@ __global__ __launch_bounds__(256) void l1_partial_kernel(size_t n, const float* 
     }
     if (i < n4) {
         const float4 x0 = a4[i], y0 = b4[i];
+        if (GRAD) d4[i] = make_float4(sgn(x0.x - y0.x), sgn(x0.y - y0.y), sgn(x0.z - y0.z), sgn(x0.w - y0.w));
         acc0 += fabsf(x0.x - y0.x); acc1 += fabsf(x0.y - y0.y); acc2 += fabsf(x0.z - y0.z); acc3 += fabsf(x0.w - y0.w);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (size_t t = n4 << 2; t < n; t++) acc0 += fabsf(a[t] - b[t]);
+        for (size_t t = n4 << 2; t < n; t++) {
+            acc0 += fabsf(a[t] - b[t]);
+            if (GRAD) d_a[t] = sgn(a[t] - b[t]);
+        }
     const float t = block_sum_256((acc0 + acc1) + (acc2 + acc3), s);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
@@ -196,7 +211,18 @@ size_t gs4d_l1_loss_scratch_bytes(void) { return (size_t)L1_BLOCKS * sizeof(floa
 
 int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream)
 {
+    return gs4d_l1_loss_forward_grad(n, a, b, scratch, loss, nullptr, nullptr, stream);
+}
+
+}  // extern "C"
+int gs4d_l1_loss_forward_grad(size_t n, const float* a, const float* b, float* scratch, float* loss, const float* g_scale,
+                              float* d_a, void* stream)
+{
     GS4D_TRACE_SCOPE("gs4d_l1_loss_forward");
+    if ((g_scale != nullptr) != (d_a != nullptr) || ((uintptr_t)d_a & 15)) {
+        gs4d_set_error("gs4d_l1_loss_forward: the gradient output needs its scale (and 16-byte alignment)");
+        return GS4D_EINVAL;
+    }
     if (n == 0 || !a || !b || !scratch || !loss) {
         gs4d_set_error("gs4d_l1_loss_forward: empty input or null pointer");
         return GS4D_EINVAL;
@@ -207,11 +233,15 @@ int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratc
     }
     hipStream_t s = (hipStream_t)stream;
     GS4D_PROF("l1_loss_forward", s);
-    hipLaunchKernelGGL(l1_partial_kernel, dim3(L1_BLOCKS), dim3(256), 0, s, n, a, b, scratch);
+    if (d_a)
+        hipLaunchKernelGGL(l1_partial_kernel<true>, dim3(L1_BLOCKS), dim3(256), 0, s, n, a, b, scratch, g_scale, d_a);
+    else
+        hipLaunchKernelGGL(l1_partial_kernel<false>, dim3(L1_BLOCKS), dim3(256), 0, s, n, a, b, scratch, g_scale, d_a);
     hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, n, scratch, loss);
     GS4D_LAUNCH_CHECK("l1_loss_forward", 0, s);
     return GS4D_OK;
 }
+extern "C" {
 
 int gs4d_l1_loss_backward(size_t n, const float* a, const float* b, const float* g_loss, float* d_a, void* stream)
 {

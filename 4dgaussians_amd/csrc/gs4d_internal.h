@@ -157,6 +157,9 @@ int gs4d_sort_direct_forced();
 // csrc/api.hip: will the calling thread's next forward bin by direct placement?  (the composite call clears the per-tile
 // counters in its activation launch then: gs4d_rasterize_forward_spec's `speculate` bit 1)
 bool gs4d_forward_bins_directly();
+// csrc/elementwise.hip: gs4d_l1_loss_forward that also writes d(g_scale[0] * loss)/da into d_a (both null: the plain forward)
+int gs4d_l1_loss_forward_grad(size_t n, const float* a, const float* b, float* scratch, float* loss, const float* g_scale,
+                              float* d_a, void* stream);
 // csrc/elementwise.hip: gs4d_activate_forward that also zeroes clear[0 .. clear_words)
 int gs4d_activate_forward_clear(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
                                 float* scales, float* rotations_n, float* opacity, uint32_t* clear, size_t clear_words,

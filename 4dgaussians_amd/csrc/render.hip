@@ -33,6 +33,7 @@ struct FwdArena {
     float *scales_a, *rot_n, *opacity_a; // activated
     char *geom, *image;
     float* l1_scratch;
+    float* l1_grad;                      // d(l1_grad_scale * L1)/dcolor, left by the forward's loss launch (desc.l1_grad_scale)
     size_t geom_bytes, image_bytes, bytes;
 };
 
@@ -56,6 +57,7 @@ FwdArena carve_forward(const gs4d_render_desc* r, char* base)
     a.image_bytes = gs4d_image_bytes(r->width, r->height);
     a.image = c.take<char>(a.image_bytes);
     if (r->target) a.l1_scratch = c.take<float>(gs4d_l1_loss_scratch_bytes() / sizeof(float));
+    if (r->target && r->l1_grad_scale) a.l1_grad = c.take<float>((size_t)3 * r->width * r->height);
     a.bytes = (size_t)(c.p - base) + 256;
     return a;
 }
@@ -87,7 +89,7 @@ BwdArena carve_backward(const gs4d_render_desc* r, int R, bool own_depth_zeros, 
     a.dL_drot = c.take<float>(4 * P);
     if (own_depth_zeros) a.zero_depth_img = c.take<float>(HW);
     a.zero_end = c.take<float>(0);
-    if (r->target) a.g_img = c.take<float>(3 * HW);
+    if (r->target && !r->l1_grad_scale) a.g_img = c.take<float>(3 * HW);
     if (r->deform) {
         a.d_sc = c.take<float>(3 * P);
         a.d_rot = c.take<float>(4 * P);
@@ -201,7 +203,8 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
     state->layout_rendered = layout_R;
     if (rc) return rc;
     if (r->target)
-        rc = gs4d_l1_loss_forward((size_t)3 * r->width * r->height, out_color, r->target, a.l1_scratch, loss, stream);
+        rc = gs4d_l1_loss_forward_grad((size_t)3 * r->width * r->height, out_color, r->target, a.l1_scratch, loss,
+                                       r->l1_grad_scale, a.l1_grad, stream);
     return rc;
 }
 
@@ -250,7 +253,13 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
     if (R == 0) GS4D_HIP_CHECK(hipMemsetAsync(g->dL_dmeans2D, 0, sizeof(float) * 3 * P, s));
 
     const float* g_img = dL_dcolor;
-    if (g_loss) {
+    if (g_loss && r->l1_grad_scale && g_loss != r->l1_grad_scale) {
+        gs4d_set_error("gs4d_render_backward: the forward left the loss gradient for desc.l1_grad_scale; g_loss must be that pointer");
+        return GS4D_EINVAL;
+    }
+    if (g_loss && r->l1_grad_scale && g_loss == r->l1_grad_scale) {
+        g_img = f.l1_grad;                                   // the forward's loss launch left it there (same arithmetic)
+    } else if (g_loss) {
         rc = gs4d_l1_loss_backward((size_t)3 * r->width * r->height, out_color, r->target, g_loss, b.g_img, stream);
         if (rc) return rc;
         g_img = b.g_img;

@@ -29,7 +29,7 @@ class RenderDesc(C.Structure):
                 ("prefiltered", C.c_int), ("flags", C.c_int),
                 ("background", FP), ("viewmatrix", FP), ("projmatrix", FP), ("cam_pos", FP),
                 ("xyz", FP), ("log_scales", FP), ("rotations", FP), ("opacity_logit", FP), ("shs", FP),
-                ("deform", C.POINTER(DeformDesc)), ("time", FP), ("force", FP), ("target", FP)]
+                ("deform", C.POINTER(DeformDesc)), ("time", FP), ("force", FP), ("target", FP), ("l1_grad_scale", FP)]
 
 
 class RenderState(C.Structure):
@@ -94,8 +94,9 @@ def _fill_desc(d: RenderDesc, call: RenderCall, P, M, xyz, scaling, rotation, op
     d.target = call.target.data_ptr() if call.target is not None else None
 
 
-def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, needs_grad: bool):
-    """gs4d_render_forward -> (color, radii, depth, loss or None, descriptor, state, arena)."""
+def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, needs_grad: bool, l1_grad_scale=None):
+    """gs4d_render_forward -> (color, radii, depth, loss or None, descriptor, state, arena).  l1_grad_scale (a device
+    scalar, render_step): the forward's loss launch also leaves d(scale * L1)/dcolor for the backward."""
     L = _cabi.lib()
     dev = xyz.device
     P, M = xyz.shape[0], features.shape[1]
@@ -104,6 +105,7 @@ def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, 
     if call.deform_net is not None:
         call.cfg["plan"].desc.no_grad = 0 if needs_grad else 1
     _fill_desc(d, call, P, M, xyz, scaling, rotation, opacity, features, flags)
+    d.l1_grad_scale = l1_grad_scale.data_ptr() if (l1_grad_scale is not None and call.target is not None) else None
     color = torch.empty((3, call.H, call.W), dtype=torch.float32, device=dev)
     depth = torch.empty((1, call.H, call.W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -272,7 +274,7 @@ def render_step(call: RenderCall, xyz, scaling, rotation, opacity, features, mea
     with torch.no_grad():
         buf = _BackwardBuffers(call, dev, P, M, opacity.shape)
         g_loss = _device_scalar(dev, loss_scale)
-        color, radii, depth, loss, d, state, arena = _issue_forward(call, xyz, scaling, rotation, opacity, features, True)
+        color, radii, depth, loss, d, state, arena = _issue_forward(call, xyz, scaling, rotation, opacity, features, True, g_loss)
         _issue_backward(call, d, state, color, radii, None, None, g_loss, buf)
         grads = (buf.d_xyz, buf.d_sc, buf.d_rot, buf.d_op, buf.d_shs, buf.d_m2d) + buf.param_grads(call)
         for p, g in zip((xyz, scaling, rotation, opacity, features, means2D) + tuple(call.params), grads):

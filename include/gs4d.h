@@ -402,6 +402,11 @@ typedef struct gs4d_render_desc {
     const float* force;           /* device [P] */
     const float* target;          /* device [3,H,W] (16-byte aligned) or NULL.  With a target the forward also writes
                                      loss[0] = mean |color - target| and the backward may start from g_loss. */
+    const float* l1_grad_scale;   /* device [1] or NULL (ABI 13).  With a target: the caller already knows the factor g its
+                                     backward will start from (a training step: g = the loss weight), so the forward's loss
+                                     launch also leaves d(g * L1)/dcolor = g sign(color - target) / n in the arena, and a
+                                     gs4d_render_backward called with g_loss == this pointer (value unchanged) starts from
+                                     it without a launch of its own for the loss gradient.  Same numbers either way. */
 } gs4d_render_desc;
 
 /* Filled by the forward, handed back to the backward unchanged.  `arena` (activations, geometry and image chunks) is
