@@ -627,7 +627,7 @@ int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ct
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return GS4D_OK;
     if (P < 0 || R < 0 || width <= 0 || height <= 0 || !scratch_alloc || !geom_buffer || !img_buffer ||
-        (R > 0 && !binning_buffer) || !dL_dpix || !dL_dpix_depth || !means3D || !radii) {
+        (R > 0 && !binning_buffer) || !dL_dpix || !means3D || !radii) {      // dL_dpix_depth == null: zeros (csrc/render.hip only)
         gs4d_set_error("gs4d_rasterize_backward: bad sizes or null pointer");
         return GS4D_EINVAL;
     }
@@ -673,6 +673,7 @@ int gs4d_rasterize_backward(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int 
                             float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
                             void* stream)
 {
+    if (P > 0 && !dL_dpix_depth) { gs4d_set_error("gs4d_rasterize_backward: bad sizes or null pointer"); return GS4D_EINVAL; }
     return gs4d_rasterize_backward_layout(scratch_alloc, scratch_ctx, P, D, M, R, background, width, height, means3D, shs,
                                           colors_precomp, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, projmatrix,
                                           campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer, dL_dpix,

@@ -185,12 +185,12 @@ __global__ __launch_bounds__(BWD_THREADS) void blend_backward_kernel(
     if (in0) {
         T_final.x = final_Ts[pix]; lastc0 = (int)n_contrib[pix];
         dLp0.x = dL_dpixels[pix]; dLp1.x = dL_dpixels[plane + pix]; dLp2.x = dL_dpixels[2 * plane + pix];
-        dLpd.x = dL_dpixel_depths[pix];
+        dLpd.x = dL_dpixel_depths ? dL_dpixel_depths[pix] : 0.f;      // null (composite call without a depth loss): zeros
     }
     if (in1) {
         T_final.y = final_Ts[pix + 1]; lastc1 = (int)n_contrib[pix + 1];
         dLp0.y = dL_dpixels[pix + 1]; dLp1.y = dL_dpixels[plane + pix + 1]; dLp2.y = dL_dpixels[2 * plane + pix + 1];
-        dLpd.y = dL_dpixel_depths[pix + 1];
+        dLpd.y = dL_dpixel_depths ? dL_dpixel_depths[pix + 1] : 0.f;
     }
     f2 T = T_final;
     f2 bg_dot_dpixel = {0.f, 0.f};

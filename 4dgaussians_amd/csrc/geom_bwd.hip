@@ -293,6 +293,24 @@ __device__ __forceinline__ void gaussian_backward(const GeomBwdArgs& A, int idx,
 // columns), every lane works on its own LDS row -- gradients overwrite the coefficients, sh_backward reads before it
 // writes -- and the rows leave as coalesced float4 stores.  Rows of culled and deferred Gaussians leave as zeros (the
 // deferred ones are filled in by geom_backward_big_kernel afterwards), so dL_dsh needs no clearing by the caller.
+// what gaussian_backward() writes (dL_dmean2D and the SH row apart), as zeros
+__device__ __forceinline__ void gaussian_zero_outputs(const GeomBwdArgs& A, int idx)
+{
+    A.dL_dcolor[3 * idx + 0] = 0.f; A.dL_dcolor[3 * idx + 1] = 0.f; A.dL_dcolor[3 * idx + 2] = 0.f;
+    A.dL_ddepth[idx] = 0.f;
+    A.dL_dconic[4 * idx + 0] = 0.f; A.dL_dconic[4 * idx + 1] = 0.f; A.dL_dconic[4 * idx + 2] = 0.f; A.dL_dconic[4 * idx + 3] = 0.f;
+    A.dL_dopacity[idx] = 0.f;
+    A.dL_dmean3D[3 * idx + 0] = 0.f; A.dL_dmean3D[3 * idx + 1] = 0.f; A.dL_dmean3D[3 * idx + 2] = 0.f;
+    if (A.dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) A.dL_dcov3D[6 * (size_t)idx + k] = 0.f;
+    }
+    if (A.scales != nullptr) {
+        A.dL_dscale[3 * idx + 0] = 0.f; A.dL_dscale[3 * idx + 1] = 0.f; A.dL_dscale[3 * idx + 2] = 0.f;
+        reinterpret_cast<float4*>(A.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
 #define GEOM_BLOCK 128
 #define GEOM_SH_PITCH 49
 template <bool STAGED>
@@ -319,8 +337,11 @@ __global__ __launch_bounds__(GEOM_BLOCK) void geom_backward_kernel(GeomBwdArgs A
         const uint32_t cnt = A.tiles_touched[idx];
         const uint32_t end = A.point_offsets[idx];
         if (!(radius > 0)) {
-            // dL_dmean2D is written in full (the caller may hand over uninitialised memory for it, see include/gs4d.h)
+            // dL_dmean2D is written in full (the caller may hand over uninitialised memory for it, see include/gs4d.h), and so
+            // is every other per-Gaussian output: a Gaussian that touched no tile gets its zeros here, so the composite call
+            // needs no 12 MB memset in front of its backward (csrc/render.hip; the reference's caller passes zero tensors)
             A.dL_dmean2D[3 * idx + 0] = 0.f; A.dL_dmean2D[3 * idx + 1] = 0.f; A.dL_dmean2D[3 * idx + 2] = 0.f;
+            gaussian_zero_outputs(A, idx);
         } else if (cnt > GS4D_BIG_ROWS) {
             const uint32_t slot = atomicAdd(A.big_count, 1u);
             A.big_list[slot] = (uint32_t)idx;

@@ -234,16 +234,18 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
     const FwdArena f = carve_forward(r, st->arena);
     if (f.bytes > st->arena_bytes) { gs4d_set_error("gs4d_render_backward: the state does not belong to this descriptor"); return GS4D_EINVAL; }
     const int R = st->num_rendered;
-    const BwdArena lay = carve_backward(r, R, dL_ddepth == nullptr, nullptr);
+    const BwdArena lay = carve_backward(r, R, false, nullptr);
     gs4d_note_alloc();
     char* base = (char*)alloc(alloc_ctx, lay.bytes);
     if (!base) { gs4d_set_error("gs4d_render_backward: the allocator returned NULL"); return GS4D_EALLOC; }
     if ((uintptr_t)base & 255) { gs4d_set_error("gs4d_render_backward: the scratch must be 256-byte aligned"); return GS4D_EINVAL; }
-    const BwdArena b = carve_backward(r, R, dL_ddepth == nullptr, base);
+    const BwdArena b = carve_backward(r, R, false, base);
     const size_t P = (size_t)r->P;
 
     // what the rasterizer backward accumulates into / leaves untouched for culled Gaussians starts at zero
-    GS4D_HIP_CHECK(hipMemsetAsync(b.zero_begin, 0, (size_t)((char*)b.zero_end - (char*)b.zero_begin), s));
+    // (R > 0: the per-Gaussian backward writes every element, zeros for the Gaussians that touched no tile, and the blend
+    // backward reads a null depth gradient as zeros: no memset node in front of the backward)
+    if (R == 0) GS4D_HIP_CHECK(hipMemsetAsync(b.zero_begin, 0, (size_t)((char*)b.zero_end - (char*)b.zero_begin), s));
     const float* shs_in = r->deform ? f.shs : r->shs;
     // the per-Gaussian backward writes every element of d_shs itself when its staged form applies (csrc/geom_bwd.hip)
     if (R == 0 || !gs4d_geom_backward_fills_dsh(r->M, shs_in, g->d_shs))
@@ -269,7 +271,7 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
     rc = gs4d_rasterize_backward_layout(fixed_alloc, &inst, r->P, r->D, r->M, R, r->background, r->width, r->height, m3, shs,
                                         nullptr, f.scales_a, r->scale_modifier, f.rot_n, nullptr, r->viewmatrix, r->projmatrix,
                                         r->cam_pos, r->tan_fovx, r->tan_fovy, radii, f.geom, st->binning, f.image, g_img,
-                                        dL_ddepth ? dL_ddepth : b.zero_depth_img, g->dL_dmeans2D, b.dL_dconic, b.dL_dopacity,
+                                        dL_ddepth, g->dL_dmeans2D, b.dL_dconic, b.dL_dopacity,
                                         b.dL_dcolor, b.dL_ddepth, dL_dmean3D, b.dL_dcov3D, g->d_shs, b.dL_dscale, b.dL_drot,
                                         r->flags & 1, stream, st->layout_rendered > R ? st->layout_rendered : R);
     if (rc) return rc;
