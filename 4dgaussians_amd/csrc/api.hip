@@ -400,7 +400,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
                                 float scale_modifier, const float* rotations, const float* cov3D_precomp,
                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                                 float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
-                                void* stream, int* num_rendered, int speculate, int* layout_rendered)
+                                void* stream, int* num_rendered, int speculate, int* layout_rendered, uint8_t* visible)
 {
     GS4D_TRACE_SCOPE("gs4d_rasterize_forward");
     if (layout_rendered) *layout_rendered = 0;
@@ -454,7 +454,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
     int rc = gs4d_launch_preprocess(P, D, M, means3D, scales, scale_modifier, rotations, opacities, shs,
                                     cov3D_precomp, colors_precomp, viewmatrix, projmatrix, cam_pos, width, height,
                                     tan_fovx, tan_fovy, prefiltered, radii, g, debug, s,
-                                    direct ? im.tile_cursor : nullptr, counters_cleared);
+                                    direct ? im.tile_cursor : nullptr, counters_cleared, visible);
     if (rc) return rc;
     // The one host round trip of the forward (rasterizer_impl.cu:282): num_rendered sizes the binning chunk.  The scan
     // kernel posts ONE 64-bit word (sequence | prefilter flag, num_rendered) into a pinned, coherent host mailbox and the

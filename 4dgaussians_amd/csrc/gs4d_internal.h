@@ -176,7 +176,7 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
                            float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s,
-                           uint32_t* tile_count = nullptr, bool tile_count_cleared = false);
+                           uint32_t* tile_count = nullptr, bool tile_count_cleared = false, uint8_t* visible = nullptr);
 int gs4d_launch_mark_visible(int P, const float* means3D, const float* viewmatrix, uint8_t* present, hipStream_t s);
 // csrc/api.hip: the rasterizer entry points with the speculative binning launch / an explicit binning layout (csrc/render.hip)
 int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_alloc_fn binning_alloc, void* binning_ctx,
@@ -186,7 +186,7 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
                                 float scale_modifier, const float* rotations, const float* cov3D_precomp,
                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                                 float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
-                                void* stream, int* num_rendered, int speculate, int* layout_rendered);
+                                void* stream, int* num_rendered, int speculate, int* layout_rendered, uint8_t* visible = nullptr);
 int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
                                    const float* background, int width, int height, const float* means3D, const float* shs,
                                    const float* colors_precomp, const float* scales, float scale_modifier,

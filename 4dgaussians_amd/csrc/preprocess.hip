@@ -57,7 +57,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
     int* __restrict__ radii, float2* __restrict__ means2D, float* __restrict__ depths, float* __restrict__ cov3Ds,
     float* __restrict__ rgb, float4* __restrict__ conic_opacity, uint8_t* __restrict__ clamped,
     uint32_t* __restrict__ tiles_touched, uint32_t* __restrict__ block_sums, uint32_t* __restrict__ block_area,
-    uint32_t* __restrict__ tile_count)
+    uint32_t* __restrict__ tile_count, uint8_t* __restrict__ visible)
 {
     __shared__ float s_view[16], s_proj[16], s_cam[3];
     __shared__ uint32_t s_wave_sum[GS4D_PRE_BLOCK / 64];
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(GS4D_PRE_BLOCK) void preprocess_kernel(
             bad = 1;  // reference traps here (auxiliary.h:156-160); we flag and report GS4D_EPREFILTER
         }
         radii[idx] = my_radius_i;
+        if (visible) visible[idx] = my_radius_i > 0;         // the caller's visibility filter (gs4d_render_desc::visible)
         tiles_touched[idx] = my_tiles;
     }
 
@@ -257,7 +258,7 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                            const float* cov3D_precomp, const float* colors_precomp, const float* viewmatrix,
                            const float* projmatrix, const float* cam_pos, int W, int H, float tan_fovx,
                            float tan_fovy, int prefiltered, int* radii, GeomState& g, int debug, hipStream_t s,
-                           uint32_t* tile_count, bool tile_count_cleared)
+                           uint32_t* tile_count, bool tile_count_cleared, uint8_t* visible)
 {
     GS4D_PROF("preprocess", s);
     const float focal_y = H / (2.0f * tan_fovy);
@@ -269,7 +270,7 @@ int gs4d_launch_preprocess(int P, int D, int M, const float* means3D, const floa
                        scale_modifier, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                        projmatrix, cam_pos, W, H, tan_fovx, tan_fovy, focal_x, focal_y, gx, gy, prefiltered, radii,
                        g.means2D, g.depths, g.cov3D, g.rgb, g.conic_opacity, g.clamped, g.tiles_touched,
-                       g.block_sums, g.block_area, tile_count);
+                       g.block_sums, g.block_area, tile_count, visible);
     GS4D_LAUNCH_CHECK("preprocess", debug, s);
     return GS4D_OK;
 }

@@ -196,7 +196,7 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
                                      r->background, r->width, r->height, m3, shs, nullptr, a.opacity_a, a.scales_a,
                                      r->scale_modifier, a.rot_n, nullptr, r->viewmatrix, r->projmatrix, r->cam_pos, r->tan_fovx,
                                      r->tan_fovy, r->prefiltered, out_color, out_depth, radii, r->flags, stream, &R,
-                                     1 | (tile_counters ? 2 : 0), &layout_R);
+                                     1 | (tile_counters ? 2 : 0), &layout_R, r->visible);
     state->binning = bin.last;
     state->binning_bytes = bin.last_bytes;
     state->num_rendered = R;

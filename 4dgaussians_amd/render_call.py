@@ -29,7 +29,7 @@ class RenderDesc(C.Structure):
                 ("prefiltered", C.c_int), ("flags", C.c_int),
                 ("background", FP), ("viewmatrix", FP), ("projmatrix", FP), ("cam_pos", FP),
                 ("xyz", FP), ("log_scales", FP), ("rotations", FP), ("opacity_logit", FP), ("shs", FP),
-                ("deform", C.POINTER(DeformDesc)), ("time", FP), ("force", FP), ("target", FP), ("l1_grad_scale", FP)]
+                ("deform", C.POINTER(DeformDesc)), ("time", FP), ("force", FP), ("target", FP), ("l1_grad_scale", FP), ("visible", FP)]
 
 
 class RenderState(C.Structure):
@@ -94,7 +94,8 @@ def _fill_desc(d: RenderDesc, call: RenderCall, P, M, xyz, scaling, rotation, op
     d.target = call.target.data_ptr() if call.target is not None else None
 
 
-def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, needs_grad: bool, l1_grad_scale=None):
+def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, needs_grad: bool, l1_grad_scale=None,
+                   visible=None):
     """gs4d_render_forward -> (color, radii, depth, loss or None, descriptor, state, arena).  l1_grad_scale (a device
     scalar, render_step): the forward's loss launch also leaves d(scale * L1)/dcolor for the backward."""
     L = _cabi.lib()
@@ -106,6 +107,7 @@ def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, 
         call.cfg["plan"].desc.no_grad = 0 if needs_grad else 1
     _fill_desc(d, call, P, M, xyz, scaling, rotation, opacity, features, flags)
     d.l1_grad_scale = l1_grad_scale.data_ptr() if (l1_grad_scale is not None and call.target is not None) else None
+    d.visible = visible.data_ptr() if visible is not None else None      # bool [P]: radii > 0, written by the preprocess launch
     color = torch.empty((3, call.H, call.W), dtype=torch.float32, device=dev)
     depth = torch.empty((1, call.H, call.W), dtype=torch.float32, device=dev)
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
@@ -267,14 +269,17 @@ def render_step(call: RenderCall, xyz, scaling, rotation, opacity, features, mea
     (binning, blend, loss) queued; autograd needs 0.15-0.3 ms of host time between that return and the backward call's
     first launch, so the GPU idles for 20-90 us per step at C2 (rocprofv3 kernel trace).  Here the
     gradient buffers exist before the forward call and the backward call follows it directly.
-    -> (color, radii, depth, loss); all detached, loss is the plain (unscaled) L1."""
+    -> (color, radii, depth, loss, visible); all detached, loss is the plain (unscaled) L1, visible = radii > 0 (written
+    by the forward itself)."""
     assert call.target is not None
     dev = xyz.device
     P, M = xyz.shape[0], features.shape[1]
     with torch.no_grad():
         buf = _BackwardBuffers(call, dev, P, M, opacity.shape)
         g_loss = _device_scalar(dev, loss_scale)
-        color, radii, depth, loss, d, state, arena = _issue_forward(call, xyz, scaling, rotation, opacity, features, True, g_loss)
+        visible = torch.empty((P,), dtype=torch.bool, device=dev)
+        color, radii, depth, loss, d, state, arena = _issue_forward(call, xyz, scaling, rotation, opacity, features, True, g_loss,
+                                                                    visible)
         _issue_backward(call, d, state, color, radii, None, None, g_loss, buf)
         grads = (buf.d_xyz, buf.d_sc, buf.d_rot, buf.d_op, buf.d_shs, buf.d_m2d) + buf.param_grads(call)
         for p, g in zip((xyz, scaling, rotation, opacity, features, means2D) + tuple(call.params), grads):
@@ -284,7 +289,7 @@ def render_step(call: RenderCall, xyz, scaling, rotation, opacity, features, mea
                 p.grad = g.view(p.shape) if g.shape != p.shape else g
             else:
                 p.grad.add_(g.view(p.shape))
-    return color, radii, depth, loss
+    return color, radii, depth, loss, visible
 
 
 def render_call(call: RenderCall, xyz, scaling, rotation, opacity, features, means2D):

@@ -124,8 +124,8 @@ def render_l1_step(cam: Camera, pc: GaussianParams, deform: Optional[nn.Module],
         out = _one_call(cam, pc, deform, bg_color, scaling_modifier, stage, shs_grad_hook, screenspace_points, target,
                         step_scale=float(loss_scale))
         if out is not None:
-            image, radii, depth, loss = out
-            return loss, image, screenspace_points, radii > 0, radii, depth
+            image, radii, depth, loss, visible = out         # visible = radii > 0, written by the forward itself
+            return loss, image, screenspace_points, visible, radii, depth
     with torch.enable_grad():
         loss, image, screenspace_points, vis, radii, depth = render_with_l1(cam, pc, deform, bg_color, target,
                                                                             scaling_modifier, stage, shs_grad_hook)

@@ -407,6 +407,8 @@ typedef struct gs4d_render_desc {
                                      launch also leaves d(g * L1)/dcolor = g sign(color - target) / n in the arena, and a
                                      gs4d_render_backward called with g_loss == this pointer (value unchanged) starts from
                                      it without a launch of its own for the loss gradient.  Same numbers either way. */
+    unsigned char* visible;       /* device [P] or NULL (ABI 13).  Written as radii[i] > 0: the visibility filter of
+                                     gaussian_renderer/renderer.py:221, without a compare launch over radii afterwards. */
 } gs4d_render_desc;
 
 /* Filled by the forward, handed back to the backward unchanged.  `arena` (activations, geometry and image chunks) is
