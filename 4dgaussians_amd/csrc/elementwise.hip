@@ -39,7 +39,11 @@ __global__ __launch_bounds__(256) void activate_forward_kernel(int P, const floa
     opacity[i] = 1.0f / (1.0f + expf(-opacity_logit[i]));
 }
 
-// inputs: the forward OUTPUTS (scales, opacity) and the raw rotation; any upstream gradient may be NULL
+__device__ __forceinline__ float block_sum_256(float v, float* s);
+
+// inputs: the forward OUTPUTS (scales, opacity) and the raw rotation; any upstream gradient may be NULL.
+// l1_loss != null (a training step of the composite call, GS4D_LOSS_AFTER_BACKWARD): workgroup 0 first finishes the L1
+// loss of the forward -- l1_final_kernel's sum over the partial sums, thread for thread -- which then needs no launch.
 __global__ __launch_bounds__(256) void activate_backward_kernel(int P, const float* __restrict__ scales,
                                                                 const float4* __restrict__ rot,
                                                                 const float* __restrict__ opacity,
@@ -47,8 +51,17 @@ __global__ __launch_bounds__(256) void activate_backward_kernel(int P, const flo
                                                                 const float4* __restrict__ g_rot,
                                                                 const float* __restrict__ g_opacity,
                                                                 float* __restrict__ d_log_scales, float4* __restrict__ d_rot,
-                                                                float* __restrict__ d_opacity_logit)
+                                                                float* __restrict__ d_opacity_logit,
+                                                                const float* __restrict__ l1_partial, size_t l1_n,
+                                                                float* __restrict__ l1_loss)
 {
+    if (l1_loss && blockIdx.x == 0) {                        // uniform for the workgroup
+        __shared__ float s_l1[256];
+        float acc = 0.f;
+        for (int k = threadIdx.x; k < L1_BLOCKS; k += 256) acc += l1_partial[k];
+        const float t = block_sum_256(acc, s_l1);
+        if (threadIdx.x == 0) l1_loss[0] = t / (float)l1_n;
+    }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
 #pragma unroll
@@ -191,6 +204,16 @@ int gs4d_activate_backward(int P, const float* scales, const float* rotations, c
                            const float* g_scales, const float* g_rotations_n, const float* g_opacity,
                            float* d_log_scales, float* d_rotations, float* d_opacity_logit, void* stream)
 {
+    return gs4d_activate_backward_loss(P, scales, rotations, opacity, g_scales, g_rotations_n, g_opacity, d_log_scales, d_rotations,
+                                       d_opacity_logit, nullptr, 0, nullptr, stream);
+}
+
+}  // extern "C"
+int gs4d_activate_backward_loss(int P, const float* scales, const float* rotations, const float* opacity,
+                                const float* g_scales, const float* g_rotations_n, const float* g_opacity,
+                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, const float* l1_partial,
+                                size_t l1_n, float* l1_loss, void* stream)
+{
     GS4D_TRACE_SCOPE("gs4d_activate_backward");
     if (P == 0) return GS4D_OK;
     if (P < 0 || !scales || !rotations || !opacity || !d_log_scales || !d_rotations || !d_opacity_logit ||
@@ -202,21 +225,22 @@ int gs4d_activate_backward(int P, const float* scales, const float* rotations, c
     GS4D_PROF("activate_backward", s);
     hipLaunchKernelGGL(activate_backward_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, scales,
                        (const float4*)rotations, opacity, g_scales, (const float4*)g_rotations_n, g_opacity,
-                       d_log_scales, (float4*)d_rotations, d_opacity_logit);
+                       d_log_scales, (float4*)d_rotations, d_opacity_logit, l1_partial, l1_n, l1_loss);
     GS4D_LAUNCH_CHECK("activate_backward", 0, s);
     return GS4D_OK;
 }
+extern "C" {
 
 size_t gs4d_l1_loss_scratch_bytes(void) { return (size_t)L1_BLOCKS * sizeof(float); }
 
 int gs4d_l1_loss_forward(size_t n, const float* a, const float* b, float* scratch, float* loss, void* stream)
 {
-    return gs4d_l1_loss_forward_grad(n, a, b, scratch, loss, nullptr, nullptr, stream);
+    return gs4d_l1_loss_forward_grad(n, a, b, scratch, loss, nullptr, nullptr, stream, 0);
 }
 
 }  // extern "C"
 int gs4d_l1_loss_forward_grad(size_t n, const float* a, const float* b, float* scratch, float* loss, const float* g_scale,
-                              float* d_a, void* stream)
+                              float* d_a, void* stream, int skip_final)
 {
     GS4D_TRACE_SCOPE("gs4d_l1_loss_forward");
     if ((g_scale != nullptr) != (d_a != nullptr) || ((uintptr_t)d_a & 15)) {
@@ -237,7 +261,8 @@ int gs4d_l1_loss_forward_grad(size_t n, const float* a, const float* b, float* s
         hipLaunchKernelGGL(l1_partial_kernel<true>, dim3(L1_BLOCKS), dim3(256), 0, s, n, a, b, scratch, g_scale, d_a);
     else
         hipLaunchKernelGGL(l1_partial_kernel<false>, dim3(L1_BLOCKS), dim3(256), 0, s, n, a, b, scratch, g_scale, d_a);
-    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, n, scratch, loss);
+    if (!skip_final)                                          // else: activate_backward_kernel finishes the sum (csrc/render.hip)
+        hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, s, n, scratch, loss);
     GS4D_LAUNCH_CHECK("l1_loss_forward", 0, s);
     return GS4D_OK;
 }

@@ -159,7 +159,12 @@ int gs4d_sort_direct_forced();
 bool gs4d_forward_bins_directly();
 // csrc/elementwise.hip: gs4d_l1_loss_forward that also writes d(g_scale[0] * loss)/da into d_a (both null: the plain forward)
 int gs4d_l1_loss_forward_grad(size_t n, const float* a, const float* b, float* scratch, float* loss, const float* g_scale,
-                              float* d_a, void* stream);
+                              float* d_a, void* stream, int skip_final);     // skip_final: only the partial sums, loss is not written
+// csrc/elementwise.hip: gs4d_activate_backward whose launch also finishes the L1 loss from the partial sums (l1_loss may be null)
+int gs4d_activate_backward_loss(int P, const float* scales, const float* rotations, const float* opacity,
+                                const float* g_scales, const float* g_rotations_n, const float* g_opacity,
+                                float* d_log_scales, float* d_rotations, float* d_opacity_logit, const float* l1_partial,
+                                size_t l1_n, float* l1_loss, void* stream);
 // csrc/elementwise.hip: gs4d_activate_forward that also zeroes clear[0 .. clear_words)
 int gs4d_activate_forward_clear(int P, const float* log_scales, const float* rotations, const float* opacity_logit,
                                 float* scales, float* rotations_n, float* opacity, uint32_t* clear, size_t clear_words,

@@ -203,8 +203,12 @@ int gs4d_render_forward(const gs4d_render_desc* r, gs4d_alloc_fn alloc, void* al
     state->layout_rendered = layout_R;
     if (rc) return rc;
     if (r->target)
+    {
+        const int defer = (r->flags & GS4D_LOSS_AFTER_BACKWARD) && !(r->flags & GS4D_FORWARD_ONLY);
         rc = gs4d_l1_loss_forward_grad((size_t)3 * r->width * r->height, out_color, r->target, a.l1_scratch, loss,
-                                       r->l1_grad_scale, a.l1_grad, stream);
+                                       r->l1_grad_scale, a.l1_grad, stream, defer);
+        if (defer) state->deferred_loss = loss;
+    }
     return rc;
 }
 
@@ -278,9 +282,10 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
     if (stage_fn) stage_fn(stage_ctx, GS4D_RENDER_STAGE_RASTER_DONE);
     // activations: gradients w.r.t. the (deformed) pre-activation scales / rotations and the opacity logits
     const float* rot_raw = r->deform ? f.rot : r->rotations;
-    rc = gs4d_activate_backward(r->P, f.scales_a, rot_raw, f.opacity_a, b.dL_dscale, b.dL_drot, b.dL_dopacity,
-                                r->deform ? b.d_sc : g->d_log_scales, r->deform ? b.d_rot : g->d_rotations,
-                                g->d_opacity_logit, stream);
+    rc = gs4d_activate_backward_loss(r->P, f.scales_a, rot_raw, f.opacity_a, b.dL_dscale, b.dL_drot, b.dL_dopacity,
+                                     r->deform ? b.d_sc : g->d_log_scales, r->deform ? b.d_rot : g->d_rotations,
+                                     g->d_opacity_logit, f.l1_scratch, (size_t)3 * r->width * r->height,
+                                     r->target ? st->deferred_loss : nullptr, stream);
     if (rc) return rc;
     if (!r->deform) {
         if (stage_fn) stage_fn(stage_ctx, GS4D_RENDER_STAGE_DATA_DONE);

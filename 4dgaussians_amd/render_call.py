@@ -20,6 +20,7 @@ from .scene.deformation import DeformDesc, DeformGrads
 
 FP = C.c_void_p
 FORWARD_ONLY = 2                       # GS4D_FORWARD_ONLY
+LOSS_AFTER_BACKWARD = 4                # GS4D_LOSS_AFTER_BACKWARD: the backward call finishes the loss (render_step)
 STAGE_RASTER_DONE, STAGE_DATA_DONE = 1, 2
 
 
@@ -34,7 +35,7 @@ class RenderDesc(C.Structure):
 
 class RenderState(C.Structure):
     _fields_ = [("arena", FP), ("arena_bytes", C.c_size_t), ("binning", FP), ("binning_bytes", C.c_size_t),
-                ("num_rendered", C.c_int), ("layout_rendered", C.c_int)]
+                ("num_rendered", C.c_int), ("layout_rendered", C.c_int), ("deferred_loss", FP)]
 
 
 class RenderGrads(C.Structure):
@@ -102,6 +103,8 @@ def _issue_forward(call: RenderCall, xyz, scaling, rotation, opacity, features, 
     dev = xyz.device
     P, M = xyz.shape[0], features.shape[1]
     flags = (1 if call.debug else 0) | (0 if needs_grad else FORWARD_ONLY)
+    if l1_grad_scale is not None and call.target is not None and needs_grad:
+        flags |= LOSS_AFTER_BACKWARD   # render_step: the backward follows at once
     d = RenderDesc()
     if call.deform_net is not None:
         call.cfg["plan"].desc.no_grad = 0 if needs_grad else 1

@@ -79,6 +79,7 @@ int gs4d_profile_read(const char* stage, double* total_ms, long* calls);
  * A backward on buffers of such a call reads undefined checkpoints for tiles with more than 128 entries.
  */
 #define GS4D_FORWARD_ONLY 2
+#define GS4D_LOSS_AFTER_BACKWARD 4   /* gs4d_render_desc::flags only */
 int gs4d_rasterize_forward(
     gs4d_alloc_fn geom_alloc, void* geom_ctx,
     gs4d_alloc_fn binning_alloc, void* binning_ctx,
@@ -387,7 +388,10 @@ typedef struct gs4d_render_desc {
     int width, height;
     float scale_modifier, tan_fovx, tan_fovy;
     int prefiltered;
-    int flags;                    /* as gs4d_rasterize_forward's `debug`: bit 0 debug, GS4D_FORWARD_ONLY */
+    int flags;                    /* as gs4d_rasterize_forward's `debug`: bit 0 debug, GS4D_FORWARD_ONLY; and
+                                     GS4D_LOSS_AFTER_BACKWARD (4, with a target): the caller promises that gs4d_render_backward
+                                     follows (a training step) and reads loss[0] only after it -- the forward then leaves the
+                                     loss as partial sums and a launch of the backward call finishes it, same value */
     const float* background;      /* device [3] */
     const float* viewmatrix;      /* device [16] */
     const float* projmatrix;      /* device [16] */
@@ -423,6 +427,7 @@ typedef struct gs4d_render_state {
     int num_rendered;
     int layout_rendered;          /* the count the binning chunk is laid out for (>= num_rendered: the forward issues
                                      binning and blend before it has read num_rendered, sized for the largest recent count) */
+    float* deferred_loss;         /* GS4D_LOSS_AFTER_BACKWARD: where the backward call writes the loss (ABI 13) */
 } gs4d_render_state;
 
 /* out_color [3,H,W], out_depth [1,H,W], radii [P]: written in full.  loss: device [1], required with a target.
