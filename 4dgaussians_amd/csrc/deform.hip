@@ -1595,11 +1595,14 @@ int gs4d_deform_backward_phases(const gs4d_deform_desc* d, const gs4d_deform_gra
     // planes, xyz through the planes, t'
     if (do_data) {
         GS4D_PROF("hexplane_backward", s);
+        int ft_done = 0;
         const int hrc = gs4d_hex_launch_backward(d, g, P, points, w.tprime, dfeat, l.F, dxyz_hex, gsix, hist, rank, key, rec, time,
-                                                 force, dL_dpoints, dtprime, s);
+                                                 force, dL_dpoints, dtprime, &ft_done, s);
         if (hrc) return hrc;
-        const int nred = (P + 255) / 256;
-        hipLaunchKernelGGL(ft_embed_final_kernel, dim3(1), dim3(256), 0, s, nred, dtprime, g->ft_w, g->ft_b);
+        if (!ft_done) {                                      // several batches: the sum over the partial sums is a launch of its own
+            const int nred = (P + 255) / 256;
+            hipLaunchKernelGGL(ft_embed_final_kernel, dim3(1), dim3(256), 0, s, nred, dtprime, g->ft_w, g->ft_b);
+        }
         GS4D_LAUNCH_CHECK("deform_tail_backward", 0, s);
     }
     // every weight-gradient product of the network (reads dO, dH1, dZ, dT and the forward activations)

@@ -29,4 +29,4 @@ int gs4d_hex_launch_forward(const gs4d_deform_desc* d, int P, const float* point
 int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P, const float* points,
                              const float* tprime, const float* dfeat, int ldf, float* dxyz_hex, float* gsix, int* hist,
                              int* rank, int* key, float4* rec, const float* time, const float* force, float* dL_dpoints,
-                             float* dtprime, hipStream_t s);
+                             float* dtprime, int* ft_done, hipStream_t s);   // *ft_done: d(ft_w), d(ft_b) are complete already

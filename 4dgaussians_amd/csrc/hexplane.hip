@@ -520,9 +520,28 @@ __global__ __launch_bounds__(256) void hexplane_rec_from_order_kernel(int P, int
 template <int lanes_shift>
 __global__ __launch_bounds__(256) void hexplane_backward_reduce_kernel(int P, int C, int L, PlaneTable T,
                                                                        const float4* __restrict__ rec,
-                                                                       const float* __restrict__ gsix)
+                                                                       const float* __restrict__ gsix, int ft_parts,
+                                                                       const float* __restrict__ ft_partial,
+                                                                       float* __restrict__ d_ft_w, float* __restrict__ d_ft_b)
 {
     extern __shared__ float4 s_mem[];                       // corner weights | corner indices | end-of-group partials
+    if (ft_parts && blockIdx.x == 0 && blockIdx.y == 0) {
+        // One workgroup first does what ft_embed_final_kernel (csrc/deform.hip) did in a launch of its own, thread for thread:
+        // the fixed-order sum of hexplane_coord_reduce_kernel's partial sums onto d(ft_w), d(ft_b) (t' = w0 t + w1 f + b).
+        float (*s_ft)[3] = reinterpret_cast<float (*)[3]>(s_mem);      // 3 KB of the staging area, before its first use
+        float a[3] = {0.f, 0.f, 0.f};
+        for (int q = threadIdx.x; q < ft_parts; q += 256)
+            for (int k = 0; k < 3; k++) a[k] += ft_partial[3 * (size_t)q + k];
+        for (int k = 0; k < 3; k++) s_ft[threadIdx.x][k] = a[k];
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off)
+                for (int k = 0; k < 3; k++) s_ft[threadIdx.x][k] += s_ft[threadIdx.x + off][k];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { d_ft_w[0] += s_ft[0][0]; d_ft_w[1] += s_ft[0][1]; d_ft_b[0] += s_ft[0][2]; }
+        __syncthreads();
+    }
     const int lanes = 1 << lanes_shift;
     const int pl = blockIdx.y, l = pl / 6, i = pl % 6;
     const int groups = 256 >> lanes_shift;
@@ -754,7 +773,7 @@ int gs4d_hex_launch_forward(const gs4d_deform_desc* d, int P, const float* point
 int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads* g, int P, const float* points,
                              const float* tprime, const float* dfeat, int ldf, float* dxyz_hex, float* gsix, int* hist,
                              int* rank, int* key, float4* rec, const float* time, const float* force, float* dL_dpoints,
-                             float* dtprime, hipStream_t s)
+                             float* dtprime, int* ft_done, hipStream_t s)
 {
     PlaneTable T = {};
     for (int i = 0; i < d->L * 6; i++) {
@@ -771,7 +790,7 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
     const int step_entries = (256 >> lanes_shift) * HEX_RUN;
     const size_t per_wg = (size_t)step_entries * HEX_RPW;
     const size_t lds = 2 * sizeof(float4) * step_entries + sizeof(float) * 4 * 256 + sizeof(int) * 3 * 64;
-    void (*kern)(int, int, int, PlaneTable, const float4*, const float*) =
+    void (*kern)(int, int, int, PlaneTable, const float4*, const float*, int, const float*, float*, float*) =
         lanes_shift == 2 ? hexplane_backward_reduce_kernel<2> : lanes_shift == 3 ? hexplane_backward_reduce_kernel<3> :
         lanes_shift == 4 ? hexplane_backward_reduce_kernel<4> : lanes_shift == 5 ? hexplane_backward_reduce_kernel<5> :
                            hexplane_backward_reduce_kernel<6>;
@@ -791,6 +810,8 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
     // (the batch size follows from the descriptor and P alone, so a recorded order and a later pass agree on it)
     const bool reuse_order = g->hex_order && g->hex_order_valid;
     const bool record = g->hex_order && !g->hex_order_valid;
+    const int nred = (P + 255) / 256;
+    const bool fold_ft = (size_t)P <= HB && g->ft_w && g->ft_b && (size_t)lds >= sizeof(float) * 3 * 256;   // one batch
     for (size_t p0 = 0; p0 < (size_t)P; p0 += HB) {
         const int n = (int)(((size_t)P - p0) < HB ? ((size_t)P - p0) : HB);
         if (p0 > 0) GS4D_HIP_CHECK(hipMemsetAsync(hist, 0, hist_bytes, s));     // the first batch's zeros come from pe_backward
@@ -808,6 +829,12 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
                                d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * (size_t)ldf, ldf,
                                (float4*)dxyz_hex + p0, gsix, hist, rank, key, reuse_order ? 0 : 1);
         }
+        if (fold_ft) {
+            // one batch: the per-point tail runs here, in front of the reduce launch, whose first workgroup then also adds up
+            // the t' partial sums (no ft_embed_final launch)
+            hipLaunchKernelGGL(hexplane_coord_reduce_kernel, dim3(nred), dim3(256), 0, s, P, (const float4*)dxyz_hex, d->aabb,
+                               time, force, d->use_time, d->use_force, dL_dpoints, dtprime);
+        }
         if (reuse_order) {
             const size_t ne = (size_t)d->L * HEX_SORTS * n;
             hipLaunchKernelGGL(hexplane_rec_from_order_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, n, d->L,
@@ -818,12 +845,14 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
                                pts_b, tp_b, hist, rank, key, rec, record ? g->hex_order + (size_t)d->L * HEX_SORTS * p0 : nullptr);
         }
         hipLaunchKernelGGL(kern, dim3((unsigned)(((size_t)n + per_wg - 1) / per_wg), 6 * d->L), dim3(256), lds, s, n, d->C,
-                           d->L, T, rec, gsix);
+                           d->L, T, rec, gsix, fold_ft ? nred : 0, dtprime, g->ft_w, g->ft_b);
     }
     GS4D_LAUNCH_CHECK("hexplane_backward", 0, s);
-    const int nred = (P + 255) / 256;
-    hipLaunchKernelGGL(hexplane_coord_reduce_kernel, dim3(nred), dim3(256), 0, s, P, (const float4*)dxyz_hex, d->aabb,
-                       time, force, d->use_time, d->use_force, dL_dpoints, dtprime);
-    GS4D_LAUNCH_CHECK("hexplane_coord_reduce", 0, s);
+    if (!fold_ft) {
+        hipLaunchKernelGGL(hexplane_coord_reduce_kernel, dim3(nred), dim3(256), 0, s, P, (const float4*)dxyz_hex, d->aabb,
+                           time, force, d->use_time, d->use_force, dL_dpoints, dtprime);
+        GS4D_LAUNCH_CHECK("hexplane_coord_reduce", 0, s);
+    }
+    *ft_done = fold_ft ? 1 : 0;
     return GS4D_OK;
 }
