@@ -699,6 +699,56 @@ __global__ __launch_bounds__(256) void hexplane_coord_reduce_kernel(int P, const
     if (threadIdx.x < 3) ft_partial[3 * (size_t)blockIdx.x + threadIdx.x] = s[0][threadIdx.x];
 }
 
+// hexplane_rec_from_order_kernel and hexplane_coord_reduce_kernel in one launch (one batch, cached point order: 15 of 16
+// iterations): thread t does entry t of the records and, in the first ceil(P / 256) workgroups, point t of the per-point
+// tail -- the same arithmetic as the two kernels, thread for thread.
+__global__ __launch_bounds__(256) void hexplane_rec_coord_kernel(int P, int L, const float* __restrict__ aabb,
+                                                                 const float* __restrict__ xyz, const float* __restrict__ tprime,
+                                                                 const int* __restrict__ order, float4* __restrict__ rec,
+                                                                 const float4* __restrict__ part, const float* __restrict__ time,
+                                                                 const float* __restrict__ force, int use_time, int use_force,
+                                                                 float* __restrict__ dL_dpoints, float* __restrict__ ft_partial)
+{
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < (size_t)L * HEX_SORTS * P) {
+        const int s = (int)((e / P) % HEX_SORTS);
+        const int p = min(max(order[e], 0), P - 1);
+        float pts[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float lo = aabb[a], hi = aabb[3 + a];
+            pts[a] = (xyz[3 * (size_t)p + a] - lo) * (2.0f / (hi - lo)) - 1.0f;
+        }
+        const float ra = s == 1 ? pts[1] : pts[0], rb = s == 0 ? pts[1] : pts[2];
+        rec[e] = make_float4(__int_as_float(p), ra, rb, tprime[p]);
+    }
+    if ((size_t)blockIdx.x * 256 >= (size_t)P) return;      // uniform: the per-point tail belongs to the first workgroups
+    __shared__ float s[256][3];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (p < P) {
+        const float4 u = part[p];
+        const float d[3] = {u.x, u.y, u.z};
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float lo = aabb[a], hi = aabb[3 + a];
+            dL_dpoints[3 * (size_t)p + a] += d[a] * (2.0f / (hi - lo));
+        }
+        const float g = u.w;
+        a0 = g * (use_time ? time[p] : 0.f);
+        a1 = g * (use_force ? force[p] : 0.f);
+        a2 = g;
+    }
+    s[threadIdx.x][0] = a0; s[threadIdx.x][1] = a1; s[threadIdx.x][2] = a2;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 3; k++) s[threadIdx.x][k] += s[threadIdx.x + off][k];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) ft_partial[3 * (size_t)blockIdx.x + threadIdx.x] = s[0][threadIdx.x];
+}
+
 }  // namespace
 
 // GS4D_HEX_CORNERS=private (tests / experiments): every lane computes its point's corner sets itself, as before round 3
@@ -829,13 +879,19 @@ int gs4d_hex_launch_backward(const gs4d_deform_desc* d, const gs4d_deform_grads*
                                d->C, d->L, lpp_shift, T, B, d->aabb, pts_b, tp_b, dfeat + p0 * (size_t)ldf, ldf,
                                (float4*)dxyz_hex + p0, gsix, hist, rank, key, reuse_order ? 0 : 1);
         }
-        if (fold_ft) {
+        if (fold_ft && !reuse_order) {
             // one batch: the per-point tail runs here, in front of the reduce launch, whose first workgroup then also adds up
             // the t' partial sums (no ft_embed_final launch)
             hipLaunchKernelGGL(hexplane_coord_reduce_kernel, dim3(nred), dim3(256), 0, s, P, (const float4*)dxyz_hex, d->aabb,
                                time, force, d->use_time, d->use_force, dL_dpoints, dtprime);
         }
-        if (reuse_order) {
+        if (reuse_order && fold_ft) {
+            // ... and with the cached point order it shares the launch that rebuilds the records
+            const size_t ne = (size_t)d->L * HEX_SORTS * n;
+            hipLaunchKernelGGL(hexplane_rec_coord_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, n, d->L,
+                               d->aabb, pts_b, tp_b, g->hex_order + (size_t)d->L * HEX_SORTS * p0, rec, (const float4*)dxyz_hex,
+                               time, force, d->use_time, d->use_force, dL_dpoints, dtprime);
+        } else if (reuse_order) {
             const size_t ne = (size_t)d->L * HEX_SORTS * n;
             hipLaunchKernelGGL(hexplane_rec_from_order_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, s, n, d->L,
                                d->aabb, pts_b, tp_b, g->hex_order + (size_t)d->L * HEX_SORTS * p0, rec);
