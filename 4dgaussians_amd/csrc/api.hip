@@ -621,7 +621,7 @@ int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ct
                                    const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
                                    float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
                                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                                   void* stream, int layout_rendered)
+                                   void* stream, int layout_rendered, const Gs4dActBwd* act)
 {
     GS4D_TRACE_SCOPE("gs4d_rasterize_backward");
     hipStream_t s = (hipStream_t)stream;
@@ -658,7 +658,7 @@ int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ct
     return gs4d_launch_geom_backward(P, D, M, R, width, height, means3D, radii, shs, scales, rotations,
                                      scale_modifier, cov3D, viewmatrix, projmatrix, tan_fovx, tan_fovy, campos, g, b,
                                      inst_grad, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_ddepth, dL_dmean3D,
-                                     dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, s);
+                                     dL_dcov3D, dL_dsh, dL_dscale, dL_drot, debug, s, act);
 }
 extern "C" {
 

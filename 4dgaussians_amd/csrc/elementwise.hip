@@ -14,8 +14,11 @@
 // The loss reduction is deterministic: fixed grid, fixed-order tree per workgroup, fixed-order
 // final pass (no float atomics).
 #include "gs4d_internal.h"
+#include "gs4d_math.h"
 
-#define L1_BLOCKS 512
+using namespace gs4d;
+
+#define L1_BLOCKS GS4D_L1_BLOCKS
 
 namespace {
 
@@ -39,7 +42,6 @@ __global__ __launch_bounds__(256) void activate_forward_kernel(int P, const floa
     opacity[i] = 1.0f / (1.0f + expf(-opacity_logit[i]));
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* s);
 
 // inputs: the forward OUTPUTS (scales, opacity) and the raw rotation; any upstream gradient may be NULL.
 // l1_loss != null (a training step of the composite call, GS4D_LOSS_AFTER_BACKWARD): workgroup 0 first finishes the L1
@@ -57,46 +59,13 @@ __global__ __launch_bounds__(256) void activate_backward_kernel(int P, const flo
 {
     if (l1_loss && blockIdx.x == 0) {                        // uniform for the workgroup
         __shared__ float s_l1[256];
-        float acc = 0.f;
-        for (int k = threadIdx.x; k < L1_BLOCKS; k += 256) acc += l1_partial[k];
-        const float t = block_sum_256(acc, s_l1);
-        if (threadIdx.x == 0) l1_loss[0] = t / (float)l1_n;
+        l1_finish(l1_partial, l1_n, l1_loss, s_l1);
     }
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-        d_log_scales[3 * (size_t)i + a] = g_scales ? g_scales[3 * (size_t)i + a] * scales[3 * (size_t)i + a] : 0.f;
-    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (g_rot) {
-        const float4 q = rot[i], g = g_rot[i];
-        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
-        if (len > 1e-12f) {
-            const float inv = 1.0f / len;
-            const float4 u = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
-            const float ug = u.x * g.x + u.y * g.y + u.z * g.z + u.w * g.w;
-            d = make_float4((g.x - u.x * ug) * inv, (g.y - u.y * ug) * inv, (g.z - u.z * ug) * inv, (g.w - u.w * ug) * inv);
-        } else {
-            d = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);   // the clamp is active: q / eps
-        }
-    }
-    d_rot[i] = d;
-    const float o = opacity[i];
-    d_opacity_logit[i] = g_opacity ? g_opacity[i] * o * (1.0f - o) : 0.f;
+    activation_backward_point(i, scales, rot, opacity, g_scales, g_rot, g_opacity, d_log_scales, d_rot, d_opacity_logit);
 }
 
-__device__ __forceinline__ float block_sum_256(float v, float* s)
-{
-    const int tid = threadIdx.x;
-    s[tid] = v;
-    __syncthreads();
-#pragma unroll
-    for (int off = 128; off >= 1; off >>= 1) {
-        if (tid < off) s[tid] += s[tid + off];
-        __syncthreads();
-    }
-    return s[0];
-}
 
 // g_scale / d_a (both or neither): the launch also writes d(g * mean |a - b|)/da = g sign(a - b) / n, element for element
 // what l1_backward_kernel computes (a training step knows g before its forward: csrc/render.hip)

@@ -31,7 +31,16 @@ struct GeomBwdArgs {
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor; float* dL_ddepth;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
     uint32_t* big_list; uint32_t* big_count;
+    Gs4dActBwd act; int has_act;             // the composite call's activation backward, applied per Gaussian (gs4d_internal.h)
 };
+
+// the activation backward of Gaussian idx from the dL_dscale / dL_drot / dL_dopacity this thread has just written
+__device__ __forceinline__ void gaussian_activation_backward(const GeomBwdArgs& A, int idx)
+{
+    activation_backward_point(idx, A.act.scales_a, reinterpret_cast<const float4*>(A.act.rot_raw), A.act.opacity_a, A.dL_dscale,
+                              reinterpret_cast<const float4*>(A.dL_drot), A.dL_dopacity, A.act.d_log_scales,
+                              reinterpret_cast<float4*>(A.act.d_rot), A.act.d_opacity_logit);
+}
 
 __device__ __forceinline__ float3 dnormvdv3(const float3 v, const float3 dv)
 {
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void geom_backward_kernel(GeomBwdArgs A
             // needs no 12 MB memset in front of its backward (csrc/render.hip; the reference's caller passes zero tensors)
             A.dL_dmean2D[3 * idx + 0] = 0.f; A.dL_dmean2D[3 * idx + 1] = 0.f; A.dL_dmean2D[3 * idx + 2] = 0.f;
             gaussian_zero_outputs(A, idx);
+            if (A.has_act) gaussian_activation_backward(A, idx);
         } else if (cnt > GS4D_BIG_ROWS) {
             const uint32_t slot = atomicAdd(A.big_count, 1u);
             A.big_list[slot] = (uint32_t)idx;
@@ -385,6 +395,7 @@ __global__ __launch_bounds__(GEOM_BLOCK) void geom_backward_kernel(GeomBwdArgs A
                 gaussian_backward(A, idx, rf, A.shs ? A.shs + (size_t)idx * A.M * 3 : nullptr,
                                   A.dL_dsh ? A.dL_dsh + (size_t)idx * A.M * 3 : nullptr);
             }
+            if (A.has_act) gaussian_activation_backward(A, idx);
         }
     }
     if (STAGED) {
@@ -403,6 +414,10 @@ __global__ __launch_bounds__(GEOM_BLOCK) void geom_backward_kernel(GeomBwdArgs A
 // a fixed-order shuffle tree combines the 64 partials and lane 0 finishes the Gaussian.
 __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
 {
+    if (A.has_act && A.act.l1_loss && blockIdx.x == 0) {     // uniform: the forward's L1 loss, finished here (GS4D_LOSS_AFTER_BACKWARD)
+        __shared__ float s_l1[256];
+        l1_finish(A.act.l1_partial, A.act.l1_n, A.act.l1_loss, s_l1);
+    }
     const int lane = threadIdx.x & 63;
     const uint32_t n_big = *A.big_count;
     const uint32_t nwaves = gridDim.x * 4u;
@@ -427,8 +442,10 @@ __global__ __launch_bounds__(256) void geom_backward_big_kernel(GeomBwdArgs A)
         float rf[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; q++) rf[q] = (float)r[q];
-        if (lane == 0)
+        if (lane == 0) {
             gaussian_backward(A, idx, rf, A.shs ? A.shs + (size_t)idx * A.M * 3 : nullptr, A.dL_dsh ? A.dL_dsh + (size_t)idx * A.M * 3 : nullptr);
+            if (A.has_act) gaussian_activation_backward(A, idx);
+        }
     }
 }
 
@@ -448,10 +465,12 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
                               const BinningState& b, const float* inst_grad, float* dL_dmean2D, float* dL_dconic,
                               float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
                               float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                              hipStream_t s)
+                              hipStream_t s, const Gs4dActBwd* act)
 {
     GS4D_PROF("geom_backward", s);
     GeomBwdArgs A;
+    A.has_act = act && scales ? 1 : 0;                       // (the folded form needs the scale / rotation gradients)
+    A.act = act ? *act : Gs4dActBwd{};
     A.P = P; A.D = D; A.M = M; A.W = W; A.H = H;
     A.means3D = means3D; A.radii = radii; A.shs = shs; A.clamped = g.clamped;
     A.scales = scales; A.rotations = rotations; A.scale_modifier = scale_modifier; A.cov3D = cov3D;

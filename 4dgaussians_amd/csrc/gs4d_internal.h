@@ -192,6 +192,16 @@ int gs4d_rasterize_forward_spec(gs4d_alloc_fn geom_alloc, void* geom_ctx, gs4d_a
                                 const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx,
                                 float tan_fovy, int prefiltered, float* out_color, float* out_depth, int* radii, int debug_arg,
                                 void* stream, int* num_rendered, int speculate, int* layout_rendered, uint8_t* visible = nullptr);
+// The activation backward of the composite call (csrc/render.hip), applied by the per-Gaussian backward itself right after
+// it has written a Gaussian's dL_dscale / dL_drot / dL_dopacity: what gs4d_activate_backward does in a launch of its own
+// (same device function: activation_backward_point, gs4d_math.h).  l1_loss != null: workgroup 0 of the deferred-Gaussian
+// launch also finishes the L1 loss (GS4D_LOSS_AFTER_BACKWARD).
+struct Gs4dActBwd {
+    const float* scales_a; const float* rot_raw; const float* opacity_a;
+    float* d_log_scales; float* d_rot; float* d_opacity_logit;
+    const float* l1_partial; size_t l1_n; float* l1_loss;
+};
+#define GS4D_L1_BLOCKS 512             // partial sums of the L1 loss (csrc/elementwise.hip)
 int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ctx, int P, int D, int M, int R,
                                    const float* background, int width, int height, const float* means3D, const float* shs,
                                    const float* colors_precomp, const float* scales, float scale_modifier,
@@ -201,7 +211,7 @@ int gs4d_rasterize_backward_layout(gs4d_alloc_fn scratch_alloc, void* scratch_ct
                                    const float* dL_dpix, const float* dL_dpix_depth, float* dL_dmean2D, float* dL_dconic,
                                    float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
                                    float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                                   void* stream, int layout_rendered);
+                                   void* stream, int layout_rendered, const Gs4dActBwd* act = nullptr);
 int gs4d_launch_binning(int P, int R, int W, int H, const int* radii, GeomState& g, BinningState& b, ImageState& im,
                         int debug, hipStream_t s, const uint32_t* R_dev = nullptr, bool direct = false);
 // the deferred-Gaussian counter of the backward scratch (layout: gs4d_backward_scratch_bytes)
@@ -225,7 +235,7 @@ int gs4d_launch_geom_backward(int P, int D, int M, int R, int W, int H, const fl
                               const BinningState& b, const float* inst_grad, float* dL_dmean2D, float* dL_dconic,
                               float* dL_dopacity, float* dL_dcolor, float* dL_ddepth, float* dL_dmean3D,
                               float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                              hipStream_t s);
+                              hipStream_t s, const Gs4dActBwd* act = nullptr);
 
 // ---- kernel experiments only (-DGS4D_TIMELINE, tools/build_timeline_lib.sh -> libgs4d_tl.so, tools/*_timeline.py): a
 // kernel records per workgroup its start / end on the 100 MHz clock, its placement and two counters of its choice

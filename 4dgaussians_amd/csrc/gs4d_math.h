@@ -205,4 +205,59 @@ __device__ __forceinline__ bool alpha_support_misses_rect(float mx, float my, fl
     return best > t * 1.001f + 1.0e-4f;                              // false for NaN
 }
 
+// Activation backward of ONE Gaussian (scene/gaussian_model.py:38-43 differentiated: exp, L2-normalise, sigmoid): the body
+// of activate_backward_kernel (csrc/elementwise.hip), also called by the per-Gaussian rasterizer backward when the
+// composite call folds the activation backward into it (csrc/geom_bwd.hip).  Inputs: the forward OUTPUTS (scales, opacity)
+// and the raw rotation; any upstream gradient array may be NULL.
+__device__ __forceinline__ void activation_backward_point(int i, const float* __restrict__ scales, const float4* __restrict__ rot,
+                                                          const float* __restrict__ opacity, const float* g_scales,
+                                                          const float4* g_rot, const float* g_opacity,
+                                                          float* __restrict__ d_log_scales, float4* __restrict__ d_rot,
+                                                          float* __restrict__ d_opacity_logit)
+{
+#pragma clang fp contract(off)         // the same rounding in every translation unit that calls it (they differ in -ffp-contract)
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        d_log_scales[3 * (size_t)i + a] = g_scales ? g_scales[3 * (size_t)i + a] * scales[3 * (size_t)i + a] : 0.f;
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (g_rot) {
+        const float4 q = rot[i], g = g_rot[i];
+        const float len = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+        if (len > 1e-12f) {
+            const float inv = 1.0f / len;
+            const float4 u = make_float4(q.x * inv, q.y * inv, q.z * inv, q.w * inv);
+            const float ug = u.x * g.x + u.y * g.y + u.z * g.z + u.w * g.w;
+            d = make_float4((g.x - u.x * ug) * inv, (g.y - u.y * ug) * inv, (g.z - u.z * ug) * inv, (g.w - u.w * ug) * inv);
+        } else {
+            d = make_float4(g.x * 1e12f, g.y * 1e12f, g.z * 1e12f, g.w * 1e12f);   // the clamp is active: q / eps
+        }
+    }
+    d_rot[i] = d;
+    const float o = opacity[i];
+    d_opacity_logit[i] = g_opacity ? g_opacity[i] * o * (1.0f - o) : 0.f;
+}
+
+// sum of v over the 256 threads of the workgroup (s: 256 floats of LDS), a fixed tree: every caller gets the same rounding
+__device__ __forceinline__ float block_sum_256(float v, float* s)
+{
+    const int tid = threadIdx.x;
+    s[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (tid < off) s[tid] += s[tid + off];
+        __syncthreads();
+    }
+    return s[0];
+}
+
+// loss[0] = (sum of the GS4D_L1_BLOCKS partial sums) / n, by one 256-thread workgroup: l1_final_kernel's arithmetic
+__device__ __forceinline__ void l1_finish(const float* __restrict__ partial, size_t n, float* __restrict__ loss, float* s256)
+{
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < 512; k += 256) acc += partial[k];
+    const float t = block_sum_256(acc, s256);
+    if (threadIdx.x == 0) loss[0] = t / (float)n;
+}
+
 }  // namespace gs4d

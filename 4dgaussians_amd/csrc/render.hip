@@ -271,17 +271,24 @@ int gs4d_render_backward(const gs4d_render_desc* r, const gs4d_render_state* st,
         g_img = b.g_img;
     }
     const float *m3 = r->deform ? f.m3 : r->xyz, *shs = r->deform ? f.shs : r->shs;
+    // activations: gradients w.r.t. the (deformed) pre-activation scales / rotations and the opacity logits.  With R > 0 the
+    // per-Gaussian backward applies them itself, Gaussian by Gaussian (and its second launch finishes a deferred loss):
+    // no launch of their own
+    const float* rot_raw = r->deform ? f.rot : r->rotations;
+    Gs4dActBwd act = {f.scales_a, rot_raw, f.opacity_a, r->deform ? b.d_sc : g->d_log_scales, r->deform ? b.d_rot : g->d_rotations,
+                      g->d_opacity_logit, f.l1_scratch, (size_t)3 * r->width * r->height, r->target ? st->deferred_loss : nullptr};
+    const bool act_folded = R > 0;
     FixedBlock inst{b.inst, b.inst_bytes};
     rc = gs4d_rasterize_backward_layout(fixed_alloc, &inst, r->P, r->D, r->M, R, r->background, r->width, r->height, m3, shs,
                                         nullptr, f.scales_a, r->scale_modifier, f.rot_n, nullptr, r->viewmatrix, r->projmatrix,
                                         r->cam_pos, r->tan_fovx, r->tan_fovy, radii, f.geom, st->binning, f.image, g_img,
                                         dL_ddepth, g->dL_dmeans2D, b.dL_dconic, b.dL_dopacity,
                                         b.dL_dcolor, b.dL_ddepth, dL_dmean3D, b.dL_dcov3D, g->d_shs, b.dL_dscale, b.dL_drot,
-                                        r->flags & 1, stream, st->layout_rendered > R ? st->layout_rendered : R);
+                                        r->flags & 1, stream, st->layout_rendered > R ? st->layout_rendered : R,
+                                        act_folded ? &act : nullptr);
     if (rc) return rc;
     if (stage_fn) stage_fn(stage_ctx, GS4D_RENDER_STAGE_RASTER_DONE);
-    // activations: gradients w.r.t. the (deformed) pre-activation scales / rotations and the opacity logits
-    const float* rot_raw = r->deform ? f.rot : r->rotations;
+    if (!act_folded)
     rc = gs4d_activate_backward_loss(r->P, f.scales_a, rot_raw, f.opacity_a, b.dL_dscale, b.dL_drot, b.dL_dopacity,
                                      r->deform ? b.d_sc : g->d_log_scales, r->deform ? b.d_rot : g->d_rotations,
                                      g->d_opacity_logit, f.l1_scratch, (size_t)3 * r->width * r->height,
